@@ -1,0 +1,85 @@
+"""ctypes binding of libblaze_hip.so (include/blaze_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There
+is no fallback of any kind: a missing library raises at first use, and a library
+without a usable GPU raises ``BlazeHipError`` from ``bz_create``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libblaze_hip.so")
+
+BZ_OPT_TIE_RULE, BZ_OPT_SHORTCUT, BZ_OPT_FORCE_GENERIC = 1, 2, 3
+BZ_F_EXACT, BZ_F_BLANK, BZ_F_AMBIG, BZ_F_GENERIC = 1, 2, 4, 8
+BZ_EXT_MAX = 64
+
+EXPORTS = [
+    "bz_abi_version", "bz_last_error", "bz_device_count", "bz_device_info", "bz_create", "bz_destroy",
+    "bz_set_option", "bz_set_whitelist", "bz_assign_submit", "bz_assign_wait", "bz_assign_stage",
+    "bz_assign_run", "bz_assign_fetch", "bz_slot_sync", "bz_slot_timing", "bz_sub_edit_distance",
+    "bz_edit_distance", "bz_counts_reset", "bz_counts_get", "bz_comm_unique_id", "bz_comm_init",
+    "bz_comm_allreduce_counts", "bz_comm_allreduce_f64", "bz_comm_destroy", "bz_valu_peak_probe",
+]
+
+
+class BlazeHipError(RuntimeError):
+    """A negative status from the C ABI (map to RuntimeError)."""
+
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library and declare every prototype.  Raises loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BlazeHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "blaze_amd has no CPU path.")
+    L = ctypes.CDLL(LIB_PATH)
+    i, i64, p, cp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_char_p
+    pi = ctypes.POINTER(ctypes.c_int)
+    sig = {
+        "bz_abi_version": ([], i),
+        "bz_last_error": ([], cp),
+        "bz_device_count": ([pi], i),
+        "bz_device_info": ([i, p, p, i], i),
+        "bz_create": ([i, ctypes.POINTER(p)], i),
+        "bz_destroy": ([p], i),
+        "bz_set_option": ([p, i, i64], i),
+        "bz_set_whitelist": ([p, p, p, i64], i),
+        "bz_assign_submit": ([p, i, p, i, p, p, p, i64, i], i),
+        "bz_assign_wait": ([p, i, p, p, p, p], i),
+        "bz_assign_stage": ([p, i, p, i, p, p, p, i64], i),
+        "bz_assign_run": ([p, i, i], i),
+        "bz_assign_fetch": ([p, i, p, p, p, p], i),
+        "bz_slot_sync": ([p, i], i),
+        "bz_slot_timing": ([p, i, p, p], i),
+        "bz_sub_edit_distance": ([p, cp, i, cp, i, i, pi], i),
+        "bz_edit_distance": ([p, cp, i, cp, i, i], i),
+        "bz_counts_reset": ([p], i),
+        "bz_counts_get": ([p, p, i64], i),
+        "bz_comm_unique_id": ([p], i),
+        "bz_comm_init": ([p, p, i, i], i),
+        "bz_comm_allreduce_counts": ([p], i),
+        "bz_comm_allreduce_f64": ([p, p, i, i], i),
+        "bz_comm_destroy": ([p], i),
+        "bz_valu_peak_probe": ([p, i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_float)], i),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(L, name)       # AttributeError if the .so lacks a declared symbol
+        fn.argtypes, fn.restype = args, res
+    _lib = L
+    return L
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        msg = load().bz_last_error()
+        raise BlazeHipError(f"libblaze_hip status {rc}: {msg.decode(errors='replace') if msg else ''}")
+    return rc

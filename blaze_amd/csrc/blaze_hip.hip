@@ -1,0 +1,573 @@
+// blaze_hip.hip -- host side of libblaze_hip.so: the C ABI declared in include/blaze_hip.h.
+// Engine = one GPU + two slots (stream, pinned staging, device buffers) + the packed whitelist
+// + the per-barcode histogram + an optional RCCL communicator (dlopen'ed, one process per GPU).
+// There is no CPU compute path in this file.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/blaze_hip.h"
+#include "scan_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(BZ_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---- RCCL through dlopen: no link-time dependency, one copy per process --------------------
+struct RcclId { char b[128]; };   // ncclUniqueId (rccl.h:40-43), passed by value
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, RcclId, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load() {
+    if (g_rccl.lib) return BZ_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *lib = nullptr;
+    for (const char *n : names) {
+        lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (lib) break;
+    }
+    if (!lib) return fail(BZ_E_RCCL, "cannot dlopen librccl: %s", dlerror());
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return fail(BZ_E_RCCL, "librccl lacks an expected symbol");
+    g_rccl.lib = lib;
+    return BZ_OK;
+}
+constexpr int kNcclSum = 0, kNcclMax = 2, kNcclInt64 = 4, kNcclFloat64 = 8;   // rccl.h:448-467
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[5] = {};
+    int64_t cap = 0;          // rows
+    int cap_stride = 0;
+    int64_t n = 0;
+    int stride = 0;
+    bool staged = false, ran = false;
+    // device
+    uint8_t *d_ext = nullptr, *d_len = nullptr, *d_off = nullptr, *d_bcl = nullptr, *d_flags = nullptr;
+    int32_t *d_hit = nullptr, *d_fast = nullptr, *d_gen = nullptr, *d_counters = nullptr;
+    int8_t *d_ed = nullptr, *d_end = nullptr;
+    // pinned host staging
+    uint8_t *h_in = nullptr, *h_out = nullptr;
+    int32_t *h_counters = nullptr;
+};
+
+}  // namespace
+
+struct bz_engine {
+    int device = 0;
+    int tie_rule = 0, shortcut = 1, force_generic = 0;
+    // whitelist
+    int64_t n_wl = -1;
+    int wl_regular = 0;
+    int n_pairs = 0;
+    uint2 *d_planes = nullptr;
+    uint32_t *d_sorted_codes = nullptr;
+    int32_t *d_sorted_idx = nullptr;
+    uint8_t *d_wl_bytes = nullptr;
+    int64_t *d_wl_off = nullptr;
+    unsigned long long *d_counts = nullptr;
+    Slot slot[BZ_SLOTS];
+    // single-pair scratch
+    uint8_t *d_pair = nullptr;
+    int32_t *d_pair_out = nullptr;
+    // comm
+    void *comm = nullptr;
+    double *d_f64 = nullptr;
+};
+
+namespace {
+
+int use(bz_handle h) {
+    if (!h) return fail(BZ_E_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    return BZ_OK;
+}
+
+void free_whitelist(bz_handle h) {
+    hipFree(h->d_planes); hipFree(h->d_sorted_codes); hipFree(h->d_sorted_idx);
+    hipFree(h->d_wl_bytes); hipFree(h->d_wl_off); hipFree(h->d_counts);
+    h->d_planes = nullptr; h->d_sorted_codes = nullptr; h->d_sorted_idx = nullptr;
+    h->d_wl_bytes = nullptr; h->d_wl_off = nullptr; h->d_counts = nullptr;
+    h->n_wl = -1;
+}
+
+void free_slot(Slot &s) {
+    hipFree(s.d_ext); hipFree(s.d_len); hipFree(s.d_off); hipFree(s.d_bcl); hipFree(s.d_flags);
+    hipFree(s.d_hit); hipFree(s.d_fast); hipFree(s.d_gen); hipFree(s.d_ed); hipFree(s.d_end);
+    hipHostFree(s.h_in); hipHostFree(s.h_out);
+    s.d_ext = s.d_len = s.d_off = s.d_bcl = s.d_flags = nullptr;
+    s.d_hit = s.d_fast = s.d_gen = nullptr;
+    s.d_ed = s.d_end = nullptr;
+    s.h_in = s.h_out = nullptr;
+    s.cap = 0; s.cap_stride = 0;
+}
+
+// input staging layout: [ext n*stride][len n][off n][bcl n]; output: [hit 4n][ed n][end n][flags n]
+int ensure_slot(Slot &s, int64_t n, int stride) {
+    if (n <= s.cap && stride <= s.cap_stride) return BZ_OK;
+    int64_t cap = std::max<int64_t>(n, s.cap);
+    cap = std::max<int64_t>(cap, 1024);
+    int cs = std::max(stride, s.cap_stride);
+    free_slot(s);
+    HIP_TRY(hipMalloc(&s.d_ext, (size_t)cap * cs));
+    HIP_TRY(hipMalloc(&s.d_len, cap)); HIP_TRY(hipMalloc(&s.d_off, cap)); HIP_TRY(hipMalloc(&s.d_bcl, cap));
+    HIP_TRY(hipMalloc(&s.d_flags, cap)); HIP_TRY(hipMalloc(&s.d_ed, cap)); HIP_TRY(hipMalloc(&s.d_end, cap));
+    HIP_TRY(hipMalloc(&s.d_hit, cap * 4)); HIP_TRY(hipMalloc(&s.d_fast, cap * 4)); HIP_TRY(hipMalloc(&s.d_gen, cap * 4));
+    HIP_TRY(hipHostMalloc(&s.h_in, (size_t)cap * (cs + 3), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&s.h_out, (size_t)cap * 7, hipHostMallocDefault));
+    s.cap = cap; s.cap_stride = cs;
+    return BZ_OK;
+}
+
+int check_slot(bz_handle h, int slot) {
+    if (int rc = use(h)) return rc;
+    if (slot < 0 || slot >= BZ_SLOTS) return fail(BZ_E_ARG, "slot %d out of range", slot);
+    return BZ_OK;
+}
+
+template <int K>
+void launch_scan(bz_handle h, Slot &s) {
+    const int block = 256;
+    const int grid = (int)((s.n + block - 1) / block);
+    hipLaunchKernelGGL(bz::k_scan_bitparallel<K>, dim3(grid), dim3(block), 0, s.stream, h->d_planes, h->n_pairs, (int)h->n_wl,
+                       s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+}
+
+}  // namespace
+
+extern "C" {
+
+int bz_abi_version(void) { return BZ_ABI_VERSION; }
+const char *bz_last_error(void) { return g_err.c_str(); }
+
+int bz_device_count(int *count) {
+    if (!count) return fail(BZ_E_ARG, "null count");
+    HIP_TRY(hipGetDeviceCount(count));
+    return BZ_OK;
+}
+
+int bz_device_info(int device, int64_t info[8], char *arch, int arch_cap) {
+    if (!info) return fail(BZ_E_ARG, "null info");
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    memset(info, 0, 8 * sizeof(int64_t));
+    info[0] = p.multiProcessorCount; info[1] = p.clockRate; info[2] = p.warpSize;
+    info[3] = (int64_t)(p.totalGlobalMem >> 20); info[4] = (int64_t)p.maxSharedMemoryPerMultiProcessor;
+    if (arch && arch_cap > 0) { strncpy(arch, p.gcnArchName, arch_cap - 1); arch[arch_cap - 1] = 0; }
+    return BZ_OK;
+}
+
+int bz_create(int device, bz_handle *out) {
+    if (!out) return fail(BZ_E_ARG, "null out");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(BZ_E_HIP, "device %d not present (%d visible): no GPU, no compute", device, n);
+    HIP_TRY(hipSetDevice(device));
+    bz_engine *h = new bz_engine();
+    h->device = device;
+    for (Slot &s : h->slot) {
+        HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        for (hipEvent_t &e : s.ev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipMalloc(&s.d_counters, 2 * sizeof(int32_t)));
+        HIP_TRY(hipHostMalloc(&s.h_counters, 2 * sizeof(int32_t), hipHostMallocDefault));
+    }
+    HIP_TRY(hipMalloc(&h->d_pair, 4096));
+    HIP_TRY(hipMalloc(&h->d_pair_out, 2 * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&h->d_f64, 64 * sizeof(double)));
+    *out = h;
+    return BZ_OK;
+}
+
+int bz_destroy(bz_handle h) {
+    if (!h) return BZ_OK;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    free_whitelist(h);
+    for (Slot &s : h->slot) {
+        free_slot(s);
+        hipFree(s.d_counters); hipHostFree(s.h_counters);
+        for (hipEvent_t &e : s.ev) if (e) hipEventDestroy(e);
+        if (s.stream) hipStreamDestroy(s.stream);
+    }
+    hipFree(h->d_pair); hipFree(h->d_pair_out); hipFree(h->d_f64);
+    delete h;
+    return BZ_OK;
+}
+
+int bz_set_option(bz_handle h, int option, int64_t value) {
+    if (!h) return fail(BZ_E_ARG, "null handle");
+    switch (option) {
+        case BZ_OPT_TIE_RULE: if (value != 0 && value != 1) return fail(BZ_E_ARG, "tie rule must be 0 or 1"); h->tie_rule = (int)value; return BZ_OK;
+        case BZ_OPT_SHORTCUT: h->shortcut = value ? 1 : 0; return BZ_OK;
+        case BZ_OPT_FORCE_GENERIC: h->force_generic = value ? 1 : 0; return BZ_OK;
+    }
+    return fail(BZ_E_ARG, "unknown option %d", option);
+}
+
+int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int64_t n) {
+    if (int rc = use(h)) return rc;
+    if (!offsets || n < 0 || (n > 0 && !bytes)) return fail(BZ_E_ARG, "bad whitelist arguments");
+    if (n > (int64_t)1 << 30) return fail(BZ_E_LIMIT, "whitelist of %lld barcodes exceeds 2^30", (long long)n);
+    for (int64_t k = 0; k < n; ++k)
+        if (offsets[k + 1] < offsets[k]) return fail(BZ_E_ARG, "offsets not monotone at %lld", (long long)k);
+    HIP_TRY(hipDeviceSynchronize());
+    free_whitelist(h);
+
+    const int64_t total = n ? offsets[n] - offsets[0] : 0;
+    bool regular = n > 0;
+    for (int64_t k = 0; k < n && regular; ++k) {
+        if (offsets[k + 1] - offsets[k] != bz::kBcLen) { regular = false; break; }
+        const char *w = bytes + offsets[k];
+        for (int i = 0; i < bz::kBcLen; ++i)
+            if (w[i] != 'A' && w[i] != 'C' && w[i] != 'G' && w[i] != 'T') { regular = false; break; }
+    }
+    // byte form (generic kernel + histogram size)
+    std::vector<int64_t> off(n + 1);
+    for (int64_t k = 0; k <= n; ++k) off[k] = offsets[k] - offsets[0];
+    HIP_TRY(hipMalloc(&h->d_wl_bytes, std::max<int64_t>(total, 1)));
+    HIP_TRY(hipMalloc(&h->d_wl_off, (n + 1) * sizeof(int64_t)));
+    if (total) HIP_TRY(hipMemcpy(h->d_wl_bytes, bytes + offsets[0], total, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_wl_off, off.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&h->d_counts, (n + 2) * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->d_counts, 0, (n + 2) * sizeof(unsigned long long)));
+
+    h->wl_regular = regular ? 1 : 0;
+    h->n_pairs = 0;
+    if (regular) {
+        // 2-bit planes, two barcodes per 32-bit word, padded to a multiple of 2 pairs with copies of
+        // barcode 0 (indices >= n are ignored by the kernel).
+        const int64_t n_pairs = ((n + 3) / 4) * 2;
+        std::vector<uint2> planes(n_pairs);
+        std::vector<uint32_t> codes(n);
+        auto plane16 = [&](int64_t k, uint32_t &hi, uint32_t &lo, uint32_t &code) {
+            const char *w = bytes + offsets[k < n ? k : 0];
+            hi = lo = code = 0;
+            for (int i = 0; i < bz::kBcLen; ++i) {
+                uint32_t c = ((uint32_t)(unsigned char)w[i] >> 1) & 3u;
+                hi |= ((c >> 1) & 1u) << i; lo |= (c & 1u) << i; code |= c << (2 * i);
+            }
+        };
+        for (int64_t p = 0; p < n_pairs; ++p) {
+            uint32_t h0, l0, c0, h1, l1, c1;
+            plane16(2 * p, h0, l0, c0); plane16(2 * p + 1, h1, l1, c1);
+            planes[p] = make_uint2(h0 | (h1 << 16), l0 | (l1 << 16));
+            if (2 * p < n) codes[2 * p] = c0;
+            if (2 * p + 1 < n) codes[2 * p + 1] = c1;
+        }
+        std::vector<int32_t> idx(n);
+        std::iota(idx.begin(), idx.end(), 0);
+        std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return codes[a] < codes[b]; });
+        std::vector<uint32_t> sorted(n);
+        for (int64_t k = 0; k < n; ++k) sorted[k] = codes[idx[k]];
+        HIP_TRY(hipMalloc(&h->d_planes, n_pairs * sizeof(uint2)));
+        HIP_TRY(hipMalloc(&h->d_sorted_codes, n * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&h->d_sorted_idx, n * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(h->d_planes, planes.data(), n_pairs * sizeof(uint2), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->d_sorted_codes, sorted.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->d_sorted_idx, idx.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+        h->n_pairs = (int)n_pairs;
+    }
+    h->n_wl = n;
+    return BZ_OK;
+}
+
+int bz_assign_stage(bz_handle h, int slot, const uint8_t *ext, int ext_stride, const uint8_t *ext_len,
+                    const uint8_t *bc_off, const uint8_t *bc_len, int64_t n) {
+    if (int rc = check_slot(h, slot)) return rc;
+    if (n < 0 || n > (int64_t)1 << 30) return fail(BZ_E_LIMIT, "row count %lld out of range", (long long)n);
+    if (n > 0 && (!ext || !ext_len || !bc_off || !bc_len)) return fail(BZ_E_ARG, "null row arrays");
+    if (ext_stride < 1 || ext_stride > BZ_EXT_MAX) return fail(BZ_E_LIMIT, "ext_stride %d outside 1..%d", ext_stride, BZ_EXT_MAX);
+    for (int64_t r = 0; r < n; ++r) {       // shapes the kernels assume, checked before any launch
+        if (ext_len[r] > ext_stride) return fail(BZ_E_ARG, "row %lld: ext_len %d > stride %d", (long long)r, ext_len[r], ext_stride);
+        if ((int)bc_off[r] + bc_len[r] > ext_len[r]) return fail(BZ_E_ARG, "row %lld: barcode outside its extension", (long long)r);
+    }
+    Slot &s = h->slot[slot];
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    if (int rc = ensure_slot(s, n, ext_stride)) return rc;
+    s.n = n; s.stride = ext_stride; s.staged = false; s.ran = false;
+    if (n) {
+        uint8_t *p = s.h_in;
+        memcpy(p, ext, (size_t)n * ext_stride); p += (size_t)n * ext_stride;
+        memcpy(p, ext_len, n); p += n;
+        memcpy(p, bc_off, n); p += n;
+        memcpy(p, bc_len, n);
+        p = s.h_in;
+        HIP_TRY(hipMemcpyAsync(s.d_ext, p, (size_t)n * ext_stride, hipMemcpyHostToDevice, s.stream)); p += (size_t)n * ext_stride;
+        HIP_TRY(hipMemcpyAsync(s.d_len, p, n, hipMemcpyHostToDevice, s.stream)); p += n;
+        HIP_TRY(hipMemcpyAsync(s.d_off, p, n, hipMemcpyHostToDevice, s.stream)); p += n;
+        HIP_TRY(hipMemcpyAsync(s.d_bcl, p, n, hipMemcpyHostToDevice, s.stream));
+    }
+    s.staged = true;
+    return BZ_OK;
+}
+
+int bz_assign_run(bz_handle h, int slot, int max_ed) {
+    if (int rc = check_slot(h, slot)) return rc;
+    Slot &s = h->slot[slot];
+    if (h->n_wl < 0) return fail(BZ_E_STATE, "bz_set_whitelist has not been called");
+    if (!s.staged) return fail(BZ_E_STATE, "slot %d has no staged rows", slot);
+    if (max_ed < 0 || max_ed > BZ_EXT_MAX) return fail(BZ_E_ARG, "max_ed %d outside 0..%d", max_ed, BZ_EXT_MAX);
+    const int n = (int)s.n;
+    HIP_TRY(hipEventRecord(s.ev[0], s.stream));
+    HIP_TRY(hipMemsetAsync(s.d_counters, 0, 2 * sizeof(int32_t), s.stream));
+    if (n) {
+        hipLaunchKernelGGL(bz::k_classify, dim3((n + 255) / 256), dim3(256), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
+                           s.d_bcl, n, h->wl_regular, h->d_sorted_codes, h->d_sorted_idx, (int)h->n_wl, h->shortcut,
+                           h->force_generic, max_ed, s.d_fast, s.d_gen, s.d_counters, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(s.ev[1], s.stream));
+    if (n && h->wl_regular && !h->force_generic && max_ed <= bz::kMaxK) {
+        switch (max_ed) {
+            case 0: launch_scan<0>(h, s); break;
+            case 1: launch_scan<1>(h, s); break;
+            case 2: launch_scan<2>(h, s); break;
+            default: launch_scan<3>(h, s); break;
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(s.ev[2], s.stream));
+    if (n) {
+        hipLaunchKernelGGL(bz::k_scan_generic, dim3((n + 63) / 64), dim3(64), 0, s.stream, h->d_wl_bytes, h->d_wl_off, (int)h->n_wl,
+                           s.d_ext, s.stride, s.d_len, s.d_off, s.d_bcl, s.d_gen, s.d_counters + 1, max_ed, h->tie_rule,
+                           h->shortcut, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(s.ev[3], s.stream));
+    if (n) {
+        hipLaunchKernelGGL(bz::k_histogram, dim3((n + 255) / 256), dim3(256), 0, s.stream, s.d_hit, n, (int)h->n_wl, h->d_counts);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(s.h_counters, s.d_counters, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(hipEventRecord(s.ev[4], s.stream));
+    s.ran = true;
+    return BZ_OK;
+}
+
+static int start_fetch(Slot &s) {
+    const int64_t n = s.n;
+    if (!n) return BZ_OK;
+    uint8_t *p = s.h_out;
+    HIP_TRY(hipMemcpyAsync(p, s.d_hit, n * 4, hipMemcpyDeviceToHost, s.stream)); p += n * 4;
+    HIP_TRY(hipMemcpyAsync(p, s.d_ed, n, hipMemcpyDeviceToHost, s.stream)); p += n;
+    HIP_TRY(hipMemcpyAsync(p, s.d_end, n, hipMemcpyDeviceToHost, s.stream)); p += n;
+    HIP_TRY(hipMemcpyAsync(p, s.d_flags, n, hipMemcpyDeviceToHost, s.stream));
+    return BZ_OK;
+}
+
+static int finish_fetch(Slot &s, int32_t *hit, int8_t *ed, int8_t *end_idx, uint8_t *flags) {
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    const int64_t n = s.n;
+    const uint8_t *p = s.h_out;
+    if (hit && n) memcpy(hit, p, n * 4);
+    p += n * 4;
+    if (ed && n) memcpy(ed, p, n);
+    p += n;
+    if (end_idx && n) memcpy(end_idx, p, n);
+    p += n;
+    if (flags && n) memcpy(flags, p, n);
+    return BZ_OK;
+}
+
+int bz_assign_submit(bz_handle h, int slot, const uint8_t *ext, int ext_stride, const uint8_t *ext_len,
+                     const uint8_t *bc_off, const uint8_t *bc_len, int64_t n, int max_ed) {
+    if (int rc = bz_assign_stage(h, slot, ext, ext_stride, ext_len, bc_off, bc_len, n)) return rc;
+    if (int rc = bz_assign_run(h, slot, max_ed)) return rc;
+    return start_fetch(h->slot[slot]);
+}
+
+int bz_assign_wait(bz_handle h, int slot, int32_t *hit, int8_t *ed, int8_t *end_idx, uint8_t *flags) {
+    if (int rc = check_slot(h, slot)) return rc;
+    Slot &s = h->slot[slot];
+    if (!s.ran) return fail(BZ_E_STATE, "slot %d has nothing submitted", slot);
+    return finish_fetch(s, hit, ed, end_idx, flags);
+}
+
+int bz_assign_fetch(bz_handle h, int slot, int32_t *hit, int8_t *ed, int8_t *end_idx, uint8_t *flags) {
+    if (int rc = check_slot(h, slot)) return rc;
+    Slot &s = h->slot[slot];
+    if (!s.ran) return fail(BZ_E_STATE, "slot %d has not run", slot);
+    if (int rc = start_fetch(s)) return rc;
+    return finish_fetch(s, hit, ed, end_idx, flags);
+}
+
+int bz_slot_sync(bz_handle h, int slot) {
+    if (int rc = check_slot(h, slot)) return rc;
+    HIP_TRY(hipStreamSynchronize(h->slot[slot].stream));
+    return BZ_OK;
+}
+
+int bz_slot_timing(bz_handle h, int slot, float ms[8], int64_t counts[8]) {
+    if (int rc = check_slot(h, slot)) return rc;
+    Slot &s = h->slot[slot];
+    if (!s.ran) return fail(BZ_E_STATE, "slot %d has not run", slot);
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    if (ms) {
+        memset(ms, 0, 8 * sizeof(float));
+        HIP_TRY(hipEventElapsedTime(&ms[0], s.ev[0], s.ev[4]));
+        for (int i = 1; i <= 4; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], s.ev[i - 1], s.ev[i]));
+    }
+    if (counts) {
+        memset(counts, 0, 8 * sizeof(int64_t));
+        counts[0] = s.n; counts[1] = s.h_counters[0]; counts[2] = s.h_counters[1]; counts[3] = h->n_wl;
+    }
+    return BZ_OK;
+}
+
+static int pair_call(bz_handle h, const char *a, int la, const char *b, int lb, int max_ed, int global_mode, int *end_idx) {
+    if (int rc = use(h)) return rc;
+    if (la < 0 || lb < 0 || (la && !a) || (lb && !b)) return fail(BZ_E_ARG, "bad operands");
+    if (std::min(la, lb) > BZ_EXT_MAX) return fail(BZ_E_LIMIT, "shorter operand longer than %d", BZ_EXT_MAX);
+    if (la + lb > 4096) return fail(BZ_E_LIMIT, "operands longer than 4096 bytes in total");
+    if (max_ed < 0) return fail(BZ_E_ARG, "negative max_ed");
+    hipStream_t st = h->slot[0].stream;
+    if (la) HIP_TRY(hipMemcpyAsync(h->d_pair, a, la, hipMemcpyHostToDevice, st));
+    if (lb) HIP_TRY(hipMemcpyAsync(h->d_pair + la, b, lb, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(bz::k_pair, dim3(1), dim3(64), 0, st, h->d_pair, la, h->d_pair + la, lb, max_ed, h->tie_rule, global_mode, h->d_pair_out);
+    HIP_TRY(hipGetLastError());
+    int32_t out[2];
+    HIP_TRY(hipMemcpyAsync(out, h->d_pair_out, sizeof out, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (end_idx) *end_idx = out[1];
+    return out[0];
+}
+
+int bz_sub_edit_distance(bz_handle h, const char *a, int la, const char *b, int lb, int max_ed, int *end_idx) {
+    return pair_call(h, a, la, b, lb, max_ed, 0, end_idx);
+}
+int bz_edit_distance(bz_handle h, const char *a, int la, const char *b, int lb, int max_ed) {
+    return pair_call(h, a, la, b, lb, max_ed, 1, nullptr);
+}
+
+int bz_counts_reset(bz_handle h) {
+    if (int rc = use(h)) return rc;
+    if (h->n_wl < 0) return fail(BZ_E_STATE, "no whitelist");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(h->d_counts, 0, (h->n_wl + 2) * sizeof(unsigned long long)));
+    return BZ_OK;
+}
+
+int bz_counts_get(bz_handle h, int64_t *out, int64_t n_out) {
+    if (int rc = use(h)) return rc;
+    if (h->n_wl < 0) return fail(BZ_E_STATE, "no whitelist");
+    if (!out || n_out != h->n_wl + 2) return fail(BZ_E_ARG, "n_out must be n_whitelist + 2");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, h->d_counts, n_out * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return BZ_OK;
+}
+
+int bz_comm_unique_id(uint8_t id[128]) {
+    if (!id) return fail(BZ_E_ARG, "null id");
+    if (int rc = rccl_load()) return rc;
+    int r = g_rccl.GetUniqueId(id);
+    if (r) return fail(BZ_E_RCCL, "ncclGetUniqueId: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    return BZ_OK;
+}
+
+int bz_comm_init(bz_handle h, const uint8_t id[128], int n_ranks, int rank) {
+    if (int rc = use(h)) return rc;
+    if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(BZ_E_ARG, "bad communicator arguments");
+    if (int rc = rccl_load()) return rc;
+    if (h->comm) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+    RcclId uid;
+    memcpy(uid.b, id, 128);
+    int r = g_rccl.CommInitRank(&h->comm, n_ranks, uid, rank);
+    if (r) { h->comm = nullptr; return fail(BZ_E_RCCL, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); }
+    return BZ_OK;
+}
+
+int bz_comm_allreduce_counts(bz_handle h) {
+    if (int rc = use(h)) return rc;
+    if (!h->comm) return fail(BZ_E_STATE, "no communicator");
+    if (h->n_wl < 0) return fail(BZ_E_STATE, "no whitelist");
+    HIP_TRY(hipDeviceSynchronize());
+    hipStream_t st = h->slot[0].stream;
+    int r = g_rccl.AllReduce(h->d_counts, h->d_counts, (size_t)h->n_wl + 2, kNcclInt64, kNcclSum, h->comm, st);
+    if (r) return fail(BZ_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    HIP_TRY(hipStreamSynchronize(st));
+    return BZ_OK;
+}
+
+int bz_comm_allreduce_f64(bz_handle h, double *inout, int n, int op) {
+    if (int rc = use(h)) return rc;
+    if (!h->comm) return fail(BZ_E_STATE, "no communicator");
+    if (!inout || n < 1 || n > 64) return fail(BZ_E_ARG, "n must be 1..64");
+    hipStream_t st = h->slot[0].stream;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyAsync(h->d_f64, inout, n * sizeof(double), hipMemcpyHostToDevice, st));
+    int r = g_rccl.AllReduce(h->d_f64, h->d_f64, (size_t)n, kNcclFloat64, op == 1 ? kNcclMax : kNcclSum, h->comm, st);
+    if (r) return fail(BZ_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    HIP_TRY(hipMemcpyAsync(inout, h->d_f64, n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return BZ_OK;
+}
+
+int bz_comm_destroy(bz_handle h) {
+    if (!h) return fail(BZ_E_ARG, "null handle");
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    h->comm = nullptr;
+    return BZ_OK;
+}
+
+int bz_valu_peak_probe(bz_handle h, int iters, double *lane_ops_per_s, float *ms_out) {
+    if (int rc = use(h)) return rc;
+    if (iters < 1 || !lane_ops_per_s) return fail(BZ_E_ARG, "bad probe arguments");
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, h->device));
+    const int blocks = p.multiProcessorCount * 8, threads = 256;
+    uint32_t *d = nullptr;
+    HIP_TRY(hipMalloc(&d, (size_t)blocks * threads * 4));
+    hipStream_t st = h->slot[0].stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    hipLaunchKernelGGL(bz::k_valu_probe, dim3(blocks), dim3(threads), 0, st, d, iters / 8 + 1, 1u);   // warm-up
+    HIP_TRY(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(bz::k_valu_probe, dim3(blocks), dim3(threads), 0, st, d, iters, 2u);
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(d);
+    *lane_ops_per_s = (double)blocks * threads * (double)iters * bz::kProbeOpsPerIter / (ms * 1e-3);
+    if (ms_out) *ms_out = ms;
+    return BZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,359 @@
+// scan_kernels.h -- device code of the MI355X (gfx950) read-to-whitelist scan.
+//
+// What it replaces: the `for i in whitelist: sub_edit_distance(i, bc, best_ed)` loop of
+// /root/reference/blaze/read_assignment.py:66-85 (N_whitelist third-party calls per read)
+// and the exact-match shortcut of :61-62.
+//
+// Design (CDNA4, wave64, integer VALU bound -- no MFMA, this is bit-vector work):
+//   * lane = read.  The read's <=20-nt extension lives in 40 VGPRs as per-column
+//     bit-plane masks (all-ones / all-zeros), constant over the whole whitelist scan.
+//   * the whitelist is packed 2 bits/base into two 16-bit planes per barcode and TWO
+//     barcodes share one 32-bit word per plane (low/high half) -> every VALU op scores two
+//     (read, barcode) pairs.  The planes are wave-uniform and are streamed through the
+//     scalar data path (s_load, read-only) so they cost no VGPRs and no vector issue slots.
+//   * per pair the kernel runs the k-error Shift-And automaton (Wu-Manber form of the
+//     Myers/Hyyro family: pure and/or/shift, no carries, so two 16-bit automata run in one
+//     32-bit register with no cross-talk: the only bit that leaks from the low half's shift
+//     lands on the high half's always-one bit).  Cost: 3 ops for the match mask + 2 + 3K ops
+//     per text column, for 2 pairs.  The automaton accepts iff the semi-global edit distance
+//     of the barcode inside the extension is <= K = max_ed.
+//   * accepting pairs are rare (~1 per read).  They take a divergent, exact path that
+//     re-runs the automaton un-packed, records the per-column distance, derives
+//     (ed, end_idx) under the configured tie rule and applies the reference's
+//     ORDER-DEPENDENT fold literally (ed<best / ed==best / 'ambiguous' / best-=1).
+//     Because each lane walks the whitelist in the caller's order, no cross-lane
+//     reduction is needed and the fold is exact by construction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bz {
+
+constexpr int kBcLen = 16;        // config.py:34
+constexpr int kTextCols = 20;     // 2 + 16 + 2 (config.py:75, read_assignment.py:70)
+constexpr int kMaxK = 3;          // bit-parallel kernels are instantiated for max_ed 0..3
+constexpr uint32_t kOne2 = 0x00010001u;
+constexpr int kHitNone = -1;
+constexpr int kHitAmbiguous = -2;
+
+constexpr unsigned kFlagExact = 1u, kFlagBlank = 2u, kFlagAmbig = 4u, kFlagGeneric = 8u;
+
+__device__ __forceinline__ uint32_t base_code(uint32_t c) { return (c >> 1) & 3u; }   // A0 C1 T2 G3
+__device__ __forceinline__ bool is_acgt(uint32_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
+
+// ------------------------------------------------------------------------------------------
+// k-error Shift-And state for one 32-bit word (two 16-bit automata when ONE = 0x00010001).
+// R[d] bit i  <=>  barcode[0..i] matches some suffix of the text read so far with <= d errors.
+// Q[d] = (R[d] << 1) | ONE is kept beside it so that a column costs 2 + 3K ops.
+template <int K, uint32_t ONE>
+struct ShiftAnd {
+    uint32_t R[K + 1], Q[K + 1];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int d = 0; d <= K; ++d) {
+            R[d] = ((1u << d) - 1u) * ONE;            // first d barcode bases deleted
+            Q[d] = ((1u << (d + 1)) - 1u) * ONE;
+        }
+    }
+    __device__ __forceinline__ void step(uint32_t eq) {
+        uint32_t oldR = R[0], oldQ = Q[0];
+        R[0] = oldQ & eq;                             // v_and
+        Q[0] = (R[0] << 1) | ONE;                     // v_lshl_or
+#pragma unroll
+        for (int d = 1; d <= K; ++d) {
+            uint32_t r = R[d], q = Q[d];
+            uint32_t t = (q & eq) | oldR;             // v_and_or : match | insertion
+            R[d] = t | oldQ | Q[d - 1];               // v_or3    : substitution | deletion
+            Q[d] = (R[d] << 1) | ONE;                 // v_lshl_or
+            oldR = r; oldQ = q;
+        }
+    }
+};
+
+// Exact (ed, end) of ONE barcode (16-bit planes bh/bl) inside the lane's text, by re-running the
+// automaton un-packed and reading the accept bit of every level at every real column.
+// cnt = number of levels whose accept bit is set = K+1-D[16][j] (levels are nested).
+template <int K>
+__device__ __forceinline__ void exact_pair(uint32_t bh, uint32_t bl, const uint32_t (&XH)[kTextCols],
+                                           const uint32_t (&XL)[kTextCols], int len, int tie, int &ed, int &end) {
+    ShiftAnd<K, 1u> A;
+    A.init();
+    int best_cnt = 0, best_end = -1;
+#pragma unroll
+    for (int j = 0; j < kTextCols; ++j) {
+        uint32_t eq = (bh ^ XH[j]) & (bl ^ XL[j]);
+        A.step(eq);
+        if (j >= kBcLen - K - 1) {
+            int cnt = 0;
+#pragma unroll
+            for (int d = 0; d <= K; ++d) cnt += (A.R[d] >> (kBcLen - 1)) & 1u;
+            bool better = (cnt > best_cnt) || (tie && cnt == best_cnt && cnt > 0);
+            if (j < len && better) { best_cnt = cnt; best_end = j; }
+        }
+    }
+    ed = K + 1 - best_cnt;
+    end = best_end;
+}
+
+// The reference's fold, literally (read_assignment.py:73-85).  hit: -1 '' / -2 'ambiguous' / index.
+__device__ __forceinline__ void fold_update(int ed, int end_idx, int idx, int &best, int &hit, int &hit_end, bool &done) {
+    if (done) return;
+    if (ed < best) { best = ed; hit = idx; hit_end = end_idx; }
+    else if (ed == best) {
+        if (hit == kHitNone) { hit = idx; hit_end = end_idx; }
+        else { hit = kHitAmbiguous; best -= 1; if (best < 0) done = true; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Bit-parallel scan: one lane = one read of `list`, every lane walks the whole whitelist in order.
+// planes[p] = {hi-bit plane, lo-bit plane} of barcodes 2p (bits 0..15) and 2p+1 (bits 16..31).
+// n_pairs is a multiple of 2 (host pads); barcodes with index >= n_wl are padding and ignored.
+template <int K>
+__global__ __launch_bounds__(256) void k_scan_bitparallel(
+    const uint2 *__restrict__ planes, int n_pairs, int n_wl, const uint8_t *__restrict__ ext, int ext_stride,
+    const uint8_t *__restrict__ ext_len, const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int tie,
+    int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
+    const int n_list = *n_list_ptr;
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((slot & ~63) >= n_list) return;                       // whole wave idle (wave-uniform)
+    const bool active = slot < n_list;
+    const int r = list[active ? slot : n_list - 1];
+    const int len = ext_len[r];
+
+    // text bit-plane masks, inverted so that eq = (BH ^ XH) & (BL ^ XL) is three plain VALU ops
+    uint32_t XH[kTextCols], XL[kTextCols];
+    const uint8_t *row = ext + (size_t)r * ext_stride;
+#pragma unroll
+    for (int j = 0; j < kTextCols; ++j) {
+        uint32_t c = (j < len) ? row[j] : (uint32_t)'A';     // columns past the text are padding
+        uint32_t code = base_code(c);
+        XH[j] = (code & 2u) ? 0u : 0xFFFFFFFFu;
+        XL[j] = (code & 1u) ? 0u : 0xFFFFFFFFu;
+    }
+
+    int best = K, hit = kHitNone, hit_end = -1;
+    bool done = !active;
+
+    for (int p = 0; p < n_pairs; p += 2) {
+        const uint2 pa = planes[p], pb = planes[p + 1];       // wave-uniform -> scalar loads
+        ShiftAnd<K, kOne2> A, B;
+        A.init();
+        B.init();
+        uint32_t HA = 0, HB = 0;
+#pragma unroll
+        for (int j = 0; j < kTextCols; ++j) {
+            A.step((pa.x ^ XH[j]) & (pa.y ^ XL[j]));
+            B.step((pb.x ^ XH[j]) & (pb.y ^ XL[j]));
+            if (j >= kBcLen - K - 1) { HA |= A.R[K]; HB |= B.R[K]; }   // first column a hit can end in
+        }
+        // accept bits: bit15 = even barcode, bit31 = odd barcode of the pair
+        uint32_t cand = ((HA >> 15) & 1u) | ((HA >> 30) & 2u) | ((HB >> 13) & 4u) | ((HB >> 28) & 8u);
+        if (done) cand = 0;
+        while (cand) {                                        // rare, divergent, exact
+            const int k = __ffs(cand) - 1;
+            cand &= cand - 1;
+            const uint2 pl = (k & 2) ? pb : pa;
+            const uint32_t sh = (k & 1) ? 16u : 0u;
+            const int idx = 2 * p + k;
+            int ed, end;
+            exact_pair<K>((pl.x >> sh) & 0xFFFFu, (pl.y >> sh) & 0xFFFFu, XH, XL, len, tie, ed, end);
+            if (ed <= K && idx < n_wl) fold_update(ed, end, idx, best, hit, hit_end, done);
+        }
+    }
+    if (active) {
+        hit_out[r] = hit >= 0 ? hit : -1;
+        ed_out[r] = (int8_t)best;
+        end_out[r] = (int8_t)(hit >= 0 ? hit_end : -1);
+        flags_out[r] = (uint8_t)(hit == kHitAmbiguous ? kFlagAmbig : 0u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Generic byte-wise semi-global DP (any alphabet, any lengths; pattern = the shorter operand,
+// the first one when equal).  Used for irregular rows / whitelists, max_ed > kMaxK and the
+// single-pair entry points.  D[0][j] = 0, D[i][0] = i, answer = min_j D[m][j], end = j-1.
+constexpr int kGenericMax = 64;   // BZ_EXT_MAX
+
+__device__ inline int dev_sub_edit_distance(const uint8_t *a, int la, const uint8_t *b, int lb, int max_ed, int tie, int &end_idx) {
+    const uint8_t *p, *t;
+    int m, n;
+    if (la <= lb) { p = a; m = la; t = b; n = lb; } else { p = b; m = lb; t = a; n = la; }
+    uint8_t col[kGenericMax + 1];
+    for (int i = 0; i <= m; ++i) col[i] = (uint8_t)i;
+    int best = m, best_end = -1;
+    for (int j = 1; j <= n; ++j) {
+        int diag = col[0];
+        col[0] = 0;
+        const uint8_t tc = t[j - 1];
+        for (int i = 1; i <= m; ++i) {
+            int left = col[i];
+            int v = diag + (p[i - 1] != tc);
+            v = min(v, (int)col[i - 1] + 1);
+            v = min(v, left + 1);
+            diag = left;
+            col[i] = (uint8_t)v;
+        }
+        int s = col[m];
+        if (s < best || (tie && s == best)) { best = s; best_end = j - 1; }
+    }
+    if (best > max_ed) { end_idx = -1; return max_ed + 1; }
+    end_idx = best_end;
+    return best;
+}
+
+// Global Levenshtein distance with cut-off; the shorter operand is the DP column (<= kGenericMax).
+__device__ inline int dev_edit_distance(const uint8_t *a, int la, const uint8_t *b, int lb, int max_ed) {
+    const uint8_t *p = a, *t = b;
+    int m = la, n = lb;
+    if (la > lb) { p = b; m = lb; t = a; n = la; }
+    uint8_t col[kGenericMax + 1];
+    for (int i = 0; i <= m; ++i) col[i] = (uint8_t)i;
+    for (int j = 1; j <= n; ++j) {
+        int diag = col[0];
+        col[0] = (uint8_t)min(j, 255);
+        const uint8_t tc = t[j - 1];
+        for (int i = 1; i <= m; ++i) {
+            int left = col[i];
+            int v = diag + (p[i - 1] != tc);
+            v = min(v, (int)col[i - 1] + 1);
+            v = min(v, left + 1);
+            diag = left;
+            col[i] = (uint8_t)min(v, 255);
+        }
+    }
+    int d = col[m];
+    return d > max_ed ? max_ed + 1 : d;
+}
+
+__global__ void k_scan_generic(const uint8_t *__restrict__ wl_bytes, const int64_t *__restrict__ wl_off, int n_wl,
+                               const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
+                               const uint8_t *__restrict__ bc_off, const uint8_t *__restrict__ bc_len,
+                               const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int max_ed, int tie,
+                               int shortcut, int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out,
+                               int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
+    const int n_list = *n_list_ptr;
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_list) return;
+    const int r = list[slot];
+    const uint8_t *row = ext + (size_t)r * ext_stride;
+    const int len = ext_len[r], off = bc_off[r], bl = bc_len[r];
+
+    if (shortcut) {                                           // `row.putative_bc in whitelist` (:61)
+        for (int k = 0; k < n_wl; ++k) {
+            const int64_t o = wl_off[k];
+            if ((int)(wl_off[k + 1] - o) != bl) continue;
+            bool same = true;
+            for (int i = 0; i < bl && same; ++i) same = wl_bytes[o + i] == row[off + i];
+            if (same) {
+                hit_out[r] = k; ed_out[r] = 0; end_out[r] = -1; flags_out[r] = (uint8_t)(kFlagExact | kFlagGeneric);
+                return;
+            }
+        }
+    }
+    int best = max_ed, hit = kHitNone, hit_end = -1;
+    bool hit_empty = false;                                   // bc_hit is the empty string (falsy in Python)
+    bool done = false;
+    for (int k = 0; k < n_wl && !done; ++k) {
+        const int64_t o = wl_off[k];
+        const int lw = (int)(wl_off[k + 1] - o);
+        int end;
+        const int ed = dev_sub_edit_distance(wl_bytes + o, lw, row, len, best, tie, end);
+        if (ed < best) { best = ed; hit = k; hit_end = end; hit_empty = (lw == 0); }
+        else if (ed == best) {
+            if (hit == kHitNone || hit_empty) { hit = k; hit_end = end; hit_empty = (lw == 0); }
+            else { hit = kHitAmbiguous; hit_empty = false; best -= 1; if (best < 0) done = true; }
+        }
+    }
+    const bool ok = hit >= 0 && !hit_empty;
+    hit_out[r] = ok ? hit : -1;
+    ed_out[r] = (int8_t)best;
+    end_out[r] = (int8_t)(ok ? hit_end : -1);
+    flags_out[r] = (uint8_t)(kFlagGeneric | (hit == kHitAmbiguous ? kFlagAmbig : 0u));
+}
+
+__global__ void k_pair(const uint8_t *a, int la, const uint8_t *b, int lb, int max_ed, int tie, int global_mode, int32_t *out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (global_mode) { out[0] = dev_edit_distance(a, la, b, lb, max_ed); out[1] = -1; }
+    else { int end; out[0] = dev_sub_edit_distance(a, la, b, lb, max_ed, tie, end); out[1] = end; }
+}
+
+// ------------------------------------------------------------------------------------------
+// Row classification + the exact-match shortcut (read_assignment.py:61-62) for regular rows:
+// binary search of the 2-bit code in the sorted whitelist (ties -> first index in caller order).
+__global__ void k_classify(const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
+                           const uint8_t *__restrict__ bc_off, const uint8_t *__restrict__ bc_len, int n, int wl_regular,
+                           const uint32_t *__restrict__ sorted_codes, const int32_t *__restrict__ sorted_idx, int n_wl,
+                           int shortcut, int force_generic, int max_ed, int32_t *__restrict__ fast_list,
+                           int32_t *__restrict__ gen_list, int32_t *__restrict__ counters, int32_t *__restrict__ hit_out,
+                           int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int len = ext_len[r], off = bc_off[r], bl = bc_len[r];
+    hit_out[r] = -1; ed_out[r] = (int8_t)min(max_ed, 127); end_out[r] = -1;
+    if (bl == 0) { flags_out[r] = (uint8_t)kFlagBlank; return; }
+    flags_out[r] = 0;
+    const uint8_t *row = ext + (size_t)r * ext_stride;
+    bool regular = wl_regular && !force_generic && bl == kBcLen && len >= kBcLen && len <= kTextCols && max_ed <= kMaxK;
+    if (regular) {
+        bool ok = true;
+        for (int j = 0; j < len; ++j) ok = ok && is_acgt(row[j]);
+        regular = ok;
+    }
+    if (!regular) { gen_list[atomicAdd(&counters[1], 1)] = r; return; }
+    if (shortcut) {
+        uint32_t code = 0;
+#pragma unroll
+        for (int i = 0; i < kBcLen; ++i) code |= base_code(row[off + i]) << (2 * i);
+        int lo = 0, hi = n_wl;                                // lower bound
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (sorted_codes[mid] < code) lo = mid + 1; else hi = mid; }
+        if (lo < n_wl && sorted_codes[lo] == code) {
+            hit_out[r] = sorted_idx[lo]; ed_out[r] = 0; flags_out[r] = (uint8_t)kFlagExact;
+            return;
+        }
+    }
+    fast_list[atomicAdd(&counters[0], 1)] = r;
+}
+
+// counts[hit] += 1 for assigned rows; counts[n_wl] += assigned, counts[n_wl+1] += rows.
+__global__ void k_histogram(const int32_t *__restrict__ hit, int n, int n_wl, unsigned long long *__restrict__ counts) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = r < n;
+    const int h = in ? hit[r] : -1;
+    if (h >= 0) atomicAdd(&counts[h], 1ull);
+    const unsigned long long m = __ballot(h >= 0);
+    const unsigned long long t = __ballot(in);
+    if ((threadIdx.x & 63) == 0) {
+        if (m) atomicAdd(&counts[n_wl], (unsigned long long)__popcll(m));
+        if (t) atomicAdd(&counts[n_wl + 1], (unsigned long long)__popcll(t));
+    }
+}
+
+// Integer-VALU ceiling probe: 8 independent chains of the scan kernel's own op mix.
+__global__ __launch_bounds__(256) void k_valu_probe(uint32_t *out, int iters, uint32_t seed) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = tid * 2654435761u + k * 40503u + seed;
+    uint32_t b = ~tid ^ seed, c = tid * 97u + 13u, d = (tid << 7) ^ 0x5bd1e995u;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t x = a[k];
+            x = (x & b) | c;          // v_and_or_b32
+            x = (x << 1) | d;         // v_lshl_or_b32
+            x = x ^ b;                // v_xor_b32
+            x = x | c | d;            // v_or3_b32  (kept data dependent by the xor above)
+            x = x & (b ^ (uint32_t)i);// v_xor + v_and
+            a[k] = x ^ (uint32_t)k;   // v_xor
+        }
+        b += 0x9e3779b9u;             // v_add
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s ^= a[k];
+    out[tid] = s;
+}
+constexpr int kProbeOpsPerIter = 8 * 7 + 1;
+
+}  // namespace bz

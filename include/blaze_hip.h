@@ -1,0 +1,133 @@
+/*
+ * blaze_hip.h -- C ABI of libblaze_hip.so, the MI355X (gfx950) read-to-whitelist
+ * assignment engine that replaces the native FFI on BLAZE's step-3 hot path.
+ *
+ * Boundary (what these entry points replace; file:line under /root/reference):
+ *   fast_edit_distance.sub_edit_distance / edit_distance  -- third-party CPython
+ *     extension (pyproject.toml:22) called once per (read, barcode) pair from
+ *     blaze/read_assignment.py:72 (N_whitelist calls per non-exact read).
+ *   The Python loop around it, blaze/read_assignment.py:61-88 (shortcut + fold),
+ *     and the process pool that fans batches out, blaze/helper.py:111-205.
+ * The Python host (blaze_amd/read_assignment.py) keeps the reference's entry
+ * points (assign_read / _assign_read_batches / _match_bc_row) and calls this
+ * ABI through ctypes.  INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions: plain pointers and sizes, caller owns every host buffer, every
+ * function returns 0 on success or a negative BZ_E* code (text of the last
+ * error on the calling thread: bz_last_error()).  No exceptions cross the
+ * boundary.  Calls on one handle are not re-entrant; two slots per handle give
+ * double buffering (submit slot 1 while slot 0 computes).  There is NO CPU
+ * fallback anywhere in this library: without a usable gfx950 device every
+ * compute entry point fails with BZ_E_HIP.
+ */
+#ifndef BLAZE_HIP_H
+#define BLAZE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bz_engine *bz_handle;
+
+#define BZ_ABI_VERSION 1
+#define BZ_EXT_MAX 64   /* longest supported extension / single-pair operand on the packed path */
+#define BZ_SLOTS 2
+
+/* error codes */
+#define BZ_OK 0
+#define BZ_E_ARG (-1)      /* bad argument (null pointer, size, option, slot) */
+#define BZ_E_HIP (-2)      /* HIP runtime error / no device */
+#define BZ_E_STATE (-3)    /* call order (no whitelist, slot empty, comm missing) */
+#define BZ_E_RCCL (-4)     /* RCCL missing or returned an error */
+#define BZ_E_LIMIT (-5)    /* size beyond a documented limit */
+
+/* options for bz_set_option */
+#define BZ_OPT_TIE_RULE 1      /* 0 = leftmost end index on ties (default), 1 = rightmost.
+                                  The only UNPINNED policy point of sub_edit_distance. */
+#define BZ_OPT_SHORTCUT 2      /* 1 (default) = exact-match shortcut of read_assignment.py:61-62;
+                                  0 = score every non-blank row (benchmark "all rows scored" mode) */
+#define BZ_OPT_FORCE_GENERIC 3 /* 1 = send every row through the byte-wise DP kernel (testing) */
+
+/* result flags (per row) */
+#define BZ_F_EXACT 1u      /* took the exact-match shortcut */
+#define BZ_F_BLANK 2u      /* empty putative_bc (`not row.putative_bc`, read_assignment.py:61) */
+#define BZ_F_AMBIG 4u      /* fold ended 'ambiguous' (read_assignment.py:82-88) */
+#define BZ_F_GENERIC 8u    /* row went through the generic DP kernel, not the bit-parallel one */
+
+/* ---- library / device ------------------------------------------------------------------ */
+int bz_abi_version(void);
+const char *bz_last_error(void);
+int bz_device_count(int *count);
+/* info[0]=compute units, [1]=max clock kHz, [2]=wavefront size, [3]=total HBM MiB, [4]=LDS bytes per CU */
+int bz_device_info(int device, int64_t info[8], char *arch, int arch_cap);
+
+/* ---- engine ---------------------------------------------------------------------------- */
+/* One engine per (process, GPU).  Replaces helper.multiprocessing_submit's worker pool
+ * (helper.py:135-139): the device, two streams and their staging buffers live here. */
+int bz_create(int device, bz_handle *out);
+int bz_destroy(bz_handle h);
+int bz_set_option(bz_handle h, int option, int64_t value);
+
+/* Whitelist upload, replaces the per-task pickled whitelist + `set(whitelist)` of
+ * read_assignment.py:206,314.  `bytes` holds the barcodes back to back, barcode k is
+ * bytes[offsets[k] .. offsets[k+1]).  ORDER IS SEMANTIC (the fold of :66-85 is
+ * order dependent) and is kept exactly as given; the caller passes list(set(whitelist)).
+ * 16-nt ACGT lists are packed 2 bits/base into the bit-plane layout the kernel streams. */
+int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int64_t n);
+
+/* Rows.  Row r is the extension ext[r*ext_stride .. +ext_len[r]) =
+ * pre_bc_flanking[-2:] + putative_bc + putative_umi[:2] (read_assignment.py:70), with
+ * putative_bc at [bc_off[r], bc_off[r]+bc_len[r]).  bc_len 0 = blank row.
+ * Outputs per row: hit = whitelist index or -1 ('' in the reference: none, ambiguous or
+ * blank); ed = final best_ed (0 for the shortcut); end_idx = bc_hit_end_idx of :76,80
+ * (umi_adj = end_idx - (ext_len-1-2), :93); flags = BZ_F_*.
+ *
+ * submit = stage + run + start the device->host copy, asynchronous on the slot's stream;
+ * wait   = block until that slot is finished and copy the results out (any out pointer may
+ *          be NULL).  Results come back in row order (helper.py:191-205's guarantee). */
+int bz_assign_submit(bz_handle h, int slot, const uint8_t *ext, int ext_stride, const uint8_t *ext_len,
+                     const uint8_t *bc_off, const uint8_t *bc_len, int64_t n, int max_ed);
+int bz_assign_wait(bz_handle h, int slot, int32_t *hit, int8_t *ed, int8_t *end_idx, uint8_t *flags);
+
+/* The same three steps separately (bench.py keeps rows resident in HBM and times `run`). */
+int bz_assign_stage(bz_handle h, int slot, const uint8_t *ext, int ext_stride, const uint8_t *ext_len,
+                    const uint8_t *bc_off, const uint8_t *bc_len, int64_t n);
+int bz_assign_run(bz_handle h, int slot, int max_ed);
+int bz_assign_fetch(bz_handle h, int slot, int32_t *hit, int8_t *ed, int8_t *end_idx, uint8_t *flags);
+int bz_slot_sync(bz_handle h, int slot);
+/* HIP-event durations (ms) of the slot's last run: ms[0] whole run, [1] classify+shortcut,
+ * [2] bit-parallel scan, [3] generic scan, [4] histogram; counts[0] rows, [1] rows scored by the
+ * bit-parallel kernel, [2] rows scored by the generic kernel, [3] whitelist size. */
+int bz_slot_timing(bz_handle h, int slot, float ms[8], int64_t counts[8]);
+
+/* Single pair on the device: the drop-in for fast_edit_distance.sub_edit_distance(a, b, max_ed)
+ * -> (ed, end_idx) and edit_distance(a, b, max_ed) -> ed (read_assignment.py:1,72; main.py:24,250).
+ * Returns the distance (max_ed+1 above the cut-off, end -1) or a negative error. */
+int bz_sub_edit_distance(bz_handle h, const char *a, int la, const char *b, int lb, int max_ed, int *end_idx);
+int bz_edit_distance(bz_handle h, const char *a, int la, const char *b, int lb, int max_ed);
+
+/* ---- per-barcode counts + the one collective -------------------------------------------- */
+/* Device-resident int64 histogram counts[0..n_wl) of assigned rows per barcode, followed by
+ * counts[n_wl] = rows assigned, counts[n_wl+1] = rows seen (the two scalars the reference sums
+ * at read_assignment.py:299-301,324-326).  Every bz_assign_run adds to it. */
+int bz_counts_reset(bz_handle h);
+int bz_counts_get(bz_handle h, int64_t *out, int64_t n_out);     /* n_out = n_wl + 2 */
+/* RCCL over xGMI, one process per GPU: rank 0 makes the id, the host passes it round,
+ * every rank inits, then the all-reduce sums the histogram in place on the device. */
+int bz_comm_unique_id(uint8_t id[128]);
+int bz_comm_init(bz_handle h, const uint8_t id[128], int n_ranks, int rank);
+int bz_comm_allreduce_counts(bz_handle h);
+int bz_comm_allreduce_f64(bz_handle h, double *inout, int n, int op); /* op 0 sum, 1 max; doubles as barrier */
+int bz_comm_destroy(bz_handle h);
+
+/* ---- measurement helper ------------------------------------------------------------------ */
+/* Independent-chain 32-bit integer VALU micro-kernel (v_and_or / v_lshl_or / v_or3 / v_xor mix):
+ * measured lane-ops per second = the empirical ceiling the scan kernel is priced against. */
+int bz_valu_peak_probe(bz_handle h, int iters, double *lane_ops_per_s, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLAZE_HIP_H */

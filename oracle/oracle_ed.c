@@ -1,0 +1,165 @@
+/*
+ * oracle_ed.c -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+ *
+ * CPU restatement (plain C, full dynamic-programming tables, no bit tricks) of
+ * the arithmetic on BLAZE's step-3 hot path.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this file's shared object, and only
+ * as the checker / the timed CPU baseline.  blaze_amd/ never loads it.
+ *
+ * What it restates
+ *   - fast_edit_distance.sub_edit_distance / edit_distance: third-party Cython
+ *     (fast-edit-distance==1.2.2, /root/reference/pyproject.toml:22), source NOT
+ *     in /root/reference and not installed.  Restated from its published
+ *     definition ("the shorter must become a substring of the longer",
+ *     /root/reference/README.md:22) and the reference's call sites
+ *     (/root/reference/blaze/read_assignment.py:72-98,
+ *      /root/reference/blaze/polyT_adaptor_finder.py:53-61,139-142,
+ *      /root/reference/blaze/main.py:250,275).
+ *     PARITY UNPINNED for: which end index is returned when several end
+ *     positions tie (policy knob `tie_rule`, default leftmost), which argument
+ *     is the pattern when both have equal length (policy: the first), and the
+ *     exact value returned above the cut-off (here max_ed+1, end -1; the
+ *     reference's fold ignores any value > its running best).
+ *   - the per-row whitelist fold, exact-match shortcut and extension of
+ *     _match_bc_row (/root/reference/blaze/read_assignment.py:35-99).  This part
+ *     IS pinned: tests/golden/ holds outputs of the real _match_bc_row /
+ *     _assign_read_batches imported from /root/reference (oracle/make_golden.py).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_TIE_LEFTMOST 0
+#define ORC_TIE_RIGHTMOST 1
+
+/* Semi-global ("substring") edit distance.
+ * pattern = the shorter of (a, b) (a when the lengths are equal), text = the
+ * other.  D[i][j] = min over s of Levenshtein(pattern[0..i), text[s..j)):
+ * D[0][j] = 0, D[i][0] = i.  Result = min_j D[m][j]; end index = j-1 (0-based,
+ * inclusive index into the LONGER string of the last aligned character; -1 when
+ * the best alignment consumes no text).  Returns max_ed+1 and end -1 when the
+ * minimum exceeds max_ed.  Call-site contract: read_assignment.py:72-98
+ * (end 17 for an indel-free hit in a 20-nt extension), polyT_adaptor_finder.py:142
+ * (+1 = position after the adaptor). */
+int orc_sub_edit_distance(const char *a, int la, const char *b, int lb,
+                          int max_ed, int tie_rule, int *end_idx)
+{
+    const char *p, *t;
+    int m, n;
+    if (la <= lb) { p = a; m = la; t = b; n = lb; }
+    else          { p = b; m = lb; t = a; n = la; }
+
+    int *col = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+    for (int i = 0; i <= m; ++i) col[i] = i;
+    int best = m, best_end = -1;           /* column 0: nothing of the text used */
+    for (int j = 1; j <= n; ++j) {
+        int diag = col[0];                  /* D[0][j-1] = 0 */
+        col[0] = 0;
+        for (int i = 1; i <= m; ++i) {
+            int up = col[i - 1];            /* D[i-1][j]   */
+            int left = col[i];              /* D[i][j-1]   */
+            int v = diag + (p[i - 1] != t[j - 1]);
+            if (up + 1 < v) v = up + 1;
+            if (left + 1 < v) v = left + 1;
+            diag = left;
+            col[i] = v;
+        }
+        if (col[m] < best || (tie_rule == ORC_TIE_RIGHTMOST && col[m] == best)) {
+            best = col[m];
+            best_end = j - 1;
+        }
+    }
+    free(col);
+    if (best > max_ed) { if (end_idx) *end_idx = -1; return max_ed + 1; }
+    if (end_idx) *end_idx = best_end;
+    return best;
+}
+
+/* Global Levenshtein distance with cut-off (main.py:250,275 call it with
+ * max_ed=5 and test `>= 5`).  Returns max_ed+1 above the cut-off (unpinned,
+ * any value > max_ed satisfies the call sites). */
+int orc_edit_distance(const char *a, int la, const char *b, int lb, int max_ed)
+{
+    int *col = (int *)malloc(sizeof(int) * (size_t)(la + 1));
+    for (int i = 0; i <= la; ++i) col[i] = i;
+    for (int j = 1; j <= lb; ++j) {
+        int diag = col[0];
+        col[0] = j;
+        for (int i = 1; i <= la; ++i) {
+            int left = col[i];
+            int v = diag + (a[i - 1] != b[j - 1]);
+            if (col[i - 1] + 1 < v) v = col[i - 1] + 1;
+            if (left + 1 < v) v = left + 1;
+            diag = left;
+            col[i] = v;
+        }
+    }
+    int d = col[la];
+    free(col);
+    return d > max_ed ? max_ed + 1 : d;
+}
+
+/* One row of _match_bc_row's scan (read_assignment.py:61-88), on explicit,
+ * ORDERED whitelist storage.
+ *   ext/ext_len : pre_bc_flanking[-2:] + putative_bc + putative_umi[:2]  (:70)
+ *   bc_off/bc_len: where putative_bc sits inside ext (for the `in whitelist`
+ *                  shortcut, :61; ignored when shortcut == 0)
+ *   wl/wl_off   : whitelist barcodes concatenated, wl_off[k]..wl_off[k+1]
+ * Outputs: *hit = whitelist index or -1 (none / ambiguous / blank), *ed_out =
+ * final best_ed (0 for the shortcut), *end_out = bc_hit_end_idx, *flag bit0 =
+ * exact shortcut taken, bit1 = blank putative_bc, bit2 = ended 'ambiguous'.
+ * An empty-string whitelist entry that becomes bc_hit is falsy in Python
+ * (`if not bc_hit`, :78; `bc_hit == ''`, :87): reproduced literally. */
+void orc_match_row(const char *ext, int ext_len, int bc_off, int bc_len,
+                   const char *wl, const int64_t *wl_off, int64_t n_wl,
+                   int max_ed, int tie_rule, int shortcut,
+                   int32_t *hit, int8_t *ed_out, int8_t *end_out, uint8_t *flag)
+{
+    *hit = -1; *ed_out = (int8_t)max_ed; *end_out = -1; *flag = 0;
+    if (bc_len == 0) { *flag = 2; return; }          /* `not row.putative_bc` */
+    if (shortcut) {
+        for (int64_t k = 0; k < n_wl; ++k) {
+            int64_t l = wl_off[k + 1] - wl_off[k];
+            if (l == bc_len && memcmp(wl + wl_off[k], ext + bc_off, (size_t)bc_len) == 0) {
+                *hit = (int32_t)k; *ed_out = 0; *end_out = -1; *flag = 1;
+                return;
+            }
+        }
+    }
+    int best = max_ed;
+    int64_t h = -1;               /* -1 '' ; -2 'ambiguous' ; >=0 index */
+    int h_end = -1;
+    for (int64_t k = 0; k < n_wl; ++k) {
+        int l = (int)(wl_off[k + 1] - wl_off[k]);
+        int e_idx;
+        int ed = orc_sub_edit_distance(wl + wl_off[k], l, ext, ext_len, best, tie_rule, &e_idx);
+        if (ed < best) {
+            best = ed; h = k; h_end = e_idx;
+        } else if (ed == best) {
+            int falsy = (h == -1) || (h >= 0 && wl_off[h + 1] == wl_off[h]);
+            if (falsy) { h = k; h_end = e_idx; }
+            else {
+                h = -2; best -= 1;
+                if (best < 0) { *flag = 4; *ed_out = (int8_t)best; return; }
+            }
+        }
+    }
+    *ed_out = (int8_t)best;
+    if (h == -2) { *flag = 4; return; }
+    if (h < 0 || wl_off[h + 1] == wl_off[h]) return;  /* '' */
+    *hit = (int32_t)h; *end_out = (int8_t)h_end;
+}
+
+/* Batch driver over rows [lo, hi) -- callers thread over row ranges. */
+void orc_match_rows(const uint8_t *ext, int ext_stride, const uint8_t *ext_len,
+                    const uint8_t *bc_off, const uint8_t *bc_len,
+                    int64_t lo, int64_t hi,
+                    const char *wl, const int64_t *wl_off, int64_t n_wl,
+                    int max_ed, int tie_rule, int shortcut,
+                    int32_t *hit, int8_t *ed_out, int8_t *end_out, uint8_t *flag)
+{
+    for (int64_t r = lo; r < hi; ++r)
+        orc_match_row((const char *)ext + r * (int64_t)ext_stride, ext_len[r], bc_off[r], bc_len[r],
+                      wl, wl_off, n_wl, max_ed, tie_rule, shortcut,
+                      hit + r, ed_out + r, end_out + r, flag + r);
+}

@@ -1,0 +1,196 @@
+"""GPU parity: the HIP scan (through the C ABI) against the CPU oracle, bit-exact.
+
+Integer / index work: the bar is equality of hit index, final best_ed, end index
+and the blank / exact / ambiguous flags on every row.
+"""
+import numpy as np
+import pytest
+
+from blaze_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+FLAG_MASK = _lib.BZ_F_EXACT | _lib.BZ_F_BLANK | _lib.BZ_F_AMBIG
+
+
+def _compare(engine, oracle, ext, el, bo, bl, wl, max_ed, tie=0, shortcut=True, force_generic=False, threads=8):
+    engine.set_option(_lib.BZ_OPT_TIE_RULE, tie)
+    engine.set_option(_lib.BZ_OPT_SHORTCUT, int(shortcut))
+    engine.set_option(_lib.BZ_OPT_FORCE_GENERIC, int(force_generic))
+    engine.set_whitelist(wl)
+    hit, ed, end, flags = engine.assign(ext, el, bo, bl, max_ed)
+    o_hit, o_ed, o_end, o_flag = oracle.match_rows(ext, el, bo, bl, wl, max_ed, tie, shortcut, threads=threads)
+    engine.set_option(_lib.BZ_OPT_TIE_RULE, 0)
+    engine.set_option(_lib.BZ_OPT_SHORTCUT, 1)
+    engine.set_option(_lib.BZ_OPT_FORCE_GENERIC, 0)
+    bad = np.flatnonzero((hit != o_hit) | (ed != o_ed) | (end != o_end) | ((flags & FLAG_MASK) != o_flag))
+    assert bad.size == 0, (
+        f"{bad.size} rows differ, first {bad[0]}: ext={bytes(ext[bad[0], :el[bad[0]]])!r} "
+        f"gpu=({hit[bad[0]]},{ed[bad[0]]},{end[bad[0]]},{flags[bad[0]]}) "
+        f"oracle=({o_hit[bad[0]]},{o_ed[bad[0]]},{o_end[bad[0]]},{o_flag[bad[0]]})")
+    return hit, ed, end, flags
+
+
+def _synthetic(n_rows, n_cells, err=1.0, seed=3, umi_len=12):
+    full = synth.full_whitelist_codes(50_000, seed=21)
+    cells = synth.cell_whitelist_codes(n_cells, full, seed=22)
+    rows = synth.make_rows(n_rows, cells, full, sub=0.01 * err, ins=0.005 * err, dele=0.005 * err, seed=seed,
+                           umi_len=umi_len)
+    return rows, synth.codes_to_bytes(cells)
+
+
+@pytest.mark.parametrize("max_ed", [0, 1, 2, 3])
+@pytest.mark.parametrize("tie", [0, 1])
+def test_bitparallel_vs_oracle(engine, oracle, max_ed, tie):
+    rows, wl = _synthetic(6000, 600, err=3.0, seed=100 + max_ed)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    wl_list = [w.tobytes() for w in wl]
+    hit, ed, end, flags = _compare(engine, oracle, ext, el, bo, bl, wl_list, max_ed, tie)
+    t = engine.timing(0)
+    assert t["rows_generic"] == 0 and t["rows_bitparallel"] > 0
+    assert (hit >= 0).sum() > 1000
+
+
+def test_all_rows_scored_mode(engine, oracle):
+    rows, wl = _synthetic(4000, 333, err=2.0, seed=7)        # odd whitelist size: exercises the padding
+    ext, el, bo, bl = synth.pack_ext(rows)
+    _compare(engine, oracle, ext, el, bo, bl, [w.tobytes() for w in wl], 2, shortcut=False)
+    t = engine.timing(0)
+    assert t["rows_bitparallel"] == int((bl > 0).sum())
+
+
+@pytest.mark.parametrize("max_ed", [2, 4, 6])
+def test_generic_kernel_vs_oracle(engine, oracle, max_ed):
+    rows, wl = _synthetic(1500, 150, err=3.0, seed=11)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    _compare(engine, oracle, ext, el, bo, bl, [w.tobytes() for w in wl], max_ed, force_generic=True)
+    t = engine.timing(0)
+    assert t["rows_bitparallel"] == 0 and t["rows_generic"] == int((bl > 0).sum())
+
+
+def test_generic_equals_bitparallel(engine):
+    rows, wl = _synthetic(3000, 257, err=4.0, seed=12)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    engine.set_whitelist([w.tobytes() for w in wl])
+    a = engine.assign(ext, el, bo, bl, 2)
+    engine.set_option(_lib.BZ_OPT_FORCE_GENERIC, 1)
+    b = engine.assign(ext, el, bo, bl, 2)
+    engine.set_option(_lib.BZ_OPT_FORCE_GENERIC, 0)
+    for x, y in zip(a[:3], b[:3]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a[3] & FLAG_MASK, b[3] & FLAG_MASK)
+
+
+def test_irregular_rows(engine, oracle):
+    """Short flanks / short UMI (ext 16..19), N and lower case, short and long putative_bc."""
+    rows, wl = _synthetic(3000, 200, err=2.0, seed=13)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    rng = np.random.default_rng(5)
+    n = ext.shape[0]
+    for r in range(n):
+        if bl[r] == 0:
+            continue
+        k = r % 8
+        if k == 1:                                  # pre flank of 1: drop the first byte
+            ext[r, :19] = ext[r, 1:20]; el[r] = 19; bo[r] = 1
+        elif k == 2:                                # no pre flank, no umi
+            ext[r, :16] = ext[r, 2:18]; el[r] = 16; bo[r] = 0
+        elif k == 3:                                # one umi base only
+            el[r] = 19
+        elif k == 4:                                # N somewhere
+            ext[r, rng.integers(0, 20)] = ord("N")
+        elif k == 5:                                # lower case base
+            j = rng.integers(0, 20); ext[r, j] = ext[r, j] | 0x20
+        elif k == 6:                                # 14-nt putative bc
+            ext[r, 16:18] = ext[r, 18:20]; el[r] = 18; bl[r] = 14
+    ext[np.arange(ext.shape[1])[None, :] >= el[:, None]] = 0
+    hit, ed, end, flags = _compare(engine, oracle, ext, el, bo, bl, [w.tobytes() for w in wl], 2)
+    t = engine.timing(0)
+    assert t["rows_generic"] > 0 and t["rows_bitparallel"] > 0
+
+
+def test_irregular_whitelist(engine, oracle):
+    """Whitelist with an N barcode, a 15-mer, an 18-mer and an empty string: generic kernel only."""
+    rows, wl = _synthetic(800, 60, err=2.0, seed=14)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    wl_list = [w.tobytes() for w in wl]
+    wl_list[3] = wl_list[3][:7] + b"N" + wl_list[3][8:]
+    wl_list[10] = wl_list[10][:15]
+    wl_list[20] = wl_list[20] + b"AC"
+    wl_list.insert(30, b"")
+    _compare(engine, oracle, ext, el, bo, bl, wl_list, 2)
+    _compare(engine, oracle, ext, el, bo, bl, wl_list, 1, tie=1)
+
+
+def test_near_duplicate_whitelist_order_dependence(engine, oracle):
+    """Dense ties: the fold is order dependent; shuffled orders must each match the oracle."""
+    base = np.frombuffer(b"ACGTACGTTGCATGCA", dtype=np.uint8)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    rng = np.random.default_rng(9)
+    wl = [base.tobytes()]
+    for p in range(16):
+        for c in acgt:
+            if c != base[p]:
+                w = base.copy(); w[p] = c; wl.append(w.tobytes())
+    for _ in range(200):
+        w = base.copy()
+        for p in rng.choice(16, size=2, replace=False):
+            w[p] = acgt[(np.flatnonzero(acgt == w[p])[0] + rng.integers(1, 4)) % 4]
+        wl.append(w.tobytes())
+    wl = list(dict.fromkeys(wl))
+    n = 2000
+    ext = np.zeros((n, 32), dtype=np.uint8)
+    for r in range(n):
+        w = base.copy()
+        for p in rng.choice(16, size=rng.integers(0, 4), replace=False):
+            w[p] = acgt[rng.integers(0, 4)]
+        ext[r, :20] = np.concatenate([acgt[rng.integers(0, 4, 2)], w, acgt[rng.integers(0, 4, 2)]])
+    el = np.full(n, 20, np.uint8); bo = np.full(n, 2, np.uint8); bl = np.full(n, 16, np.uint8)
+    outs = []
+    for seed in range(3):
+        order = list(wl)
+        np.random.default_rng(seed).shuffle(order)
+        for tie in (0, 1):
+            hit, *_ = _compare(engine, oracle, ext, el, bo, bl, order, 2, tie=tie)
+        outs.append(np.array([order[h] if h >= 0 else b"" for h in hit], dtype=object))
+    assert any((outs[0] != outs[k]).any() for k in (1, 2)), "expected at least one order-dependent row"
+
+
+def test_single_pair_entry_points(engine, oracle):
+    rng = np.random.default_rng(3)
+    alpha = "ACGTN"
+    for _ in range(300):
+        a = "".join(alpha[i] for i in rng.integers(0, 5, rng.integers(0, 20)))
+        b = "".join(alpha[i] for i in rng.integers(0, 5, rng.integers(0, 40)))
+        k = int(rng.integers(0, 6))
+        assert engine.sub_edit_distance(a, b, k) == oracle.sub_edit_distance(a, b, k), (a, b, k)
+        assert engine.edit_distance(a, b, k) == oracle.edit_distance(a, b, k), (a, b, k)
+    # the stage-1 call shape: long text first, short pattern second (polyT_adaptor_finder.py:53,139)
+    assert engine.sub_edit_distance("TTTTCTTCCGATCTACGT" * 3, "CTTCCGATCT", 2) == \
+        oracle.sub_edit_distance("TTTTCTTCCGATCTACGT" * 3, "CTTCCGATCT", 2)
+
+
+def test_empty_and_tiny_batches(engine, oracle):
+    rows, wl = _synthetic(70, 50, seed=15)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    wl_list = [w.tobytes() for w in wl]
+    engine.set_whitelist(wl_list)
+    hit, ed, end, flags = engine.assign(ext[:0], el[:0], bo[:0], bl[:0], 2)
+    assert hit.size == 0
+    for n in (1, 2, 63, 64, 65):
+        _compare(engine, oracle, ext[:n], el[:n], bo[:n], bl[:n], wl_list, 2)
+    _compare(engine, oracle, ext, el, bo, bl, wl_list[:1], 2)
+    _compare(engine, oracle, ext, el, bo, bl, wl_list[:3], 2)
+
+
+def test_counts_histogram(engine, oracle):
+    rows, wl = _synthetic(5000, 100, seed=16)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    engine.set_whitelist([w.tobytes() for w in wl])
+    engine.counts_reset()
+    hit, *_ = engine.assign(ext, el, bo, bl, 2)
+    hit2, *_ = engine.assign(ext[:1000], el[:1000], bo[:1000], bl[:1000], 2, slot=1)
+    c = engine.counts()
+    expect = np.bincount(hit[hit >= 0], minlength=100) + np.bincount(hit2[hit2 >= 0], minlength=100)
+    assert np.array_equal(c[:100], expect)
+    assert c[100] == (hit >= 0).sum() + (hit2 >= 0).sum() and c[101] == 6000

@@ -165,7 +165,7 @@ template <int K>
 void launch_scan(bz_handle h, Slot &s) {
     const int block = 256;
     const int grid = (int)((s.n + block - 1) / block);
-    hipLaunchKernelGGL(bz::k_scan_bitparallel<K>, dim3(grid), dim3(block), 0, s.stream, h->d_planes, h->n_pairs, (int)h->n_wl,
+    hipLaunchKernelGGL(bz::k_scan_bitparallel<K>, dim3(grid), dim3(block), 0, s.stream, (const uint4 *)h->d_planes, h->n_pairs, (int)h->n_wl,
                        s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
 }
 

@@ -106,12 +106,61 @@ __device__ __forceinline__ void fold_update(int ed, int end_idx, int idx, int &b
 }
 
 // ------------------------------------------------------------------------------------------
+// Full-rate instruction selection (measured on MI355X, tools/valu_microbench.hip): with all-VGPR
+// operands v_xor/v_and/v_or/v_add_u32 and the 3-input v_bitop3_b32 issue at the SIMD-32 rate
+// (~2 cycles per wave64 instruction); v_lshlrev, v_and_or, v_or3, v_lshl_or, every v_pk_* and ANY
+// instruction with an SGPR source run at half that.  So the hot loop below is written as
+//   - x+x (v_add_u32) instead of x<<1,
+//   - explicit v_bitop3_b32 truth tables instead of and_or / or3,
+//   - barcode planes and the constant 0x00010001 held in VGPRs (broadcast vector loads),
+// which makes one text column cost 2 (match mask) + 2 + 4K full-rate ops for TWO pairs.
+constexpr uint32_t kTA = 0xF0, kTB = 0xCC, kTC = 0xAA;           // LUT3 operand patterns
+#define BZ_LUT3(a, b, c, expr) __builtin_amdgcn_bitop3_b32((a), (b), (c), (uint32_t)((expr) & 0xFF))
+
+__device__ __forceinline__ uint32_t dbl(uint32_t x) {            // x << 1 at the full VALU rate
+    uint32_t s;
+    asm("v_add_u32 %0, %1, %1" : "=v"(s) : "v"(x));
+    return s;
+}
+__device__ __forceinline__ uint32_t in_vgpr(uint32_t x) {        // pin a (uniform) value into a VGPR
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// Packed k-error Shift-And in the "S = R + R" form: Q = S | ONE is never materialised, ONE rides
+// along as a bitop3 operand.  R[d]' = ((S[d]|ONE) & eq) | R[d-1] | S[d-1] | S[d-1]' | ONE.
+template <int K>
+struct PackedScan {
+    uint32_t R[K + 1], S[K + 1];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int d = 0; d <= K; ++d) { R[d] = ((1u << d) - 1u) * kOne2; S[d] = 2u * R[d]; }
+    }
+    template <bool LAST>
+    __device__ __forceinline__ void step(uint32_t eq, uint32_t one) {
+        uint32_t oldR = R[0], oldS = S[0];
+        R[0] = BZ_LUT3(oldS, one, eq, (kTA | kTB) & kTC);
+        if (!LAST || K > 0) S[0] = dbl(R[0]);
+#pragma unroll
+        for (int d = 1; d <= K; ++d) {
+            const uint32_t r = R[d], sd = S[d];
+            uint32_t t = BZ_LUT3(sd, one, eq, (kTA | kTB) & kTC);
+            t = BZ_LUT3(t, oldR, oldS, kTA | kTB | kTC);
+            R[d] = BZ_LUT3(t, S[d - 1], one, kTA | kTB | kTC);
+            if (!LAST || d < K) S[d] = dbl(R[d]);
+            oldR = r; oldS = sd;
+        }
+    }
+};
+
 // Bit-parallel scan: one lane = one read of `list`, every lane walks the whole whitelist in order.
 // planes[p] = {hi-bit plane, lo-bit plane} of barcodes 2p (bits 0..15) and 2p+1 (bits 16..31).
 // n_pairs is a multiple of 2 (host pads); barcodes with index >= n_wl are padding and ignored.
+// The planes are wave-uniform but are fetched with a (laundered) vector load so they arrive in
+// VGPRs; the next iteration's 16 bytes are requested before the current one is scored.
 template <int K>
 __global__ __launch_bounds__(256) void k_scan_bitparallel(
-    const uint2 *__restrict__ planes, int n_pairs, int n_wl, const uint8_t *__restrict__ ext, int ext_stride,
+    const uint4 *__restrict__ planes, int n_pairs, int n_wl, const uint8_t *__restrict__ ext, int ext_stride,
     const uint8_t *__restrict__ ext_len, const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int tie,
     int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
     const int n_list = *n_list_ptr;
@@ -121,7 +170,7 @@ __global__ __launch_bounds__(256) void k_scan_bitparallel(
     const int r = list[active ? slot : n_list - 1];
     const int len = ext_len[r];
 
-    // text bit-plane masks, inverted so that eq = (BH ^ XH) & (BL ^ XL) is three plain VALU ops
+    // text bit-plane masks, inverted so that eq = (BH ^ XH) & (BL ^ XL)
     uint32_t XH[kTextCols], XL[kTextCols];
     const uint8_t *row = ext + (size_t)r * ext_stride;
 #pragma unroll
@@ -131,33 +180,46 @@ __global__ __launch_bounds__(256) void k_scan_bitparallel(
         XH[j] = (code & 2u) ? 0u : 0xFFFFFFFFu;
         XL[j] = (code & 1u) ? 0u : 0xFFFFFFFFu;
     }
+    const uint32_t one = in_vgpr(kOne2);
 
     int best = K, hit = kHitNone, hit_end = -1;
     bool done = !active;
 
-    for (int p = 0; p < n_pairs; p += 2) {
-        const uint2 pa = planes[p], pb = planes[p + 1];       // wave-uniform -> scalar loads
-        ShiftAnd<K, kOne2> A, B;
+    const int n_quads = n_pairs >> 1;                         // one uint4 = two pairs = four barcodes
+    uint32_t q_idx = in_vgpr(0u);                             // divergent-looking index -> vector load
+    uint4 cur = planes[q_idx];
+    constexpr int kFirst = kBcLen - K - 1;                    // first column a hit can end in
+    for (int q = 0; q < n_quads; ++q) {
+        const uint4 pl4 = cur;
+        q_idx = in_vgpr((uint32_t)min(q + 1, n_quads - 1));
+        cur = planes[q_idx];                                  // prefetch the next four barcodes
+        PackedScan<K> A, B;
         A.init();
         B.init();
-        uint32_t HA = 0, HB = 0;
+        uint32_t HA = 0, HB = 0, PA = 0, PB = 0;
 #pragma unroll
         for (int j = 0; j < kTextCols; ++j) {
-            A.step((pa.x ^ XH[j]) & (pa.y ^ XL[j]));
-            B.step((pb.x ^ XH[j]) & (pb.y ^ XL[j]));
-            if (j >= kBcLen - K - 1) { HA |= A.R[K]; HB |= B.R[K]; }   // first column a hit can end in
+            const uint32_t eqa = BZ_LUT3(pl4.x ^ XH[j], pl4.y, XL[j], kTA & (kTB ^ kTC));
+            const uint32_t eqb = BZ_LUT3(pl4.z ^ XH[j], pl4.w, XL[j], kTA & (kTB ^ kTC));
+            if (j == kTextCols - 1) { A.template step<true>(eqa, one); B.template step<true>(eqb, one); }
+            else { A.template step<false>(eqa, one); B.template step<false>(eqb, one); }
+            if (j >= kFirst) {                                // accumulate accept bits two columns per op
+                if (((j - kFirst) & 1) == 0) { PA = A.R[K]; PB = B.R[K]; }
+                else { HA = BZ_LUT3(HA, PA, A.R[K], kTA | kTB | kTC); HB = BZ_LUT3(HB, PB, B.R[K], kTA | kTB | kTC); }
+            }
         }
+        if (((kTextCols - 1 - kFirst) & 1) == 0) { HA |= PA; HB |= PB; }
         // accept bits: bit15 = even barcode, bit31 = odd barcode of the pair
         uint32_t cand = ((HA >> 15) & 1u) | ((HA >> 30) & 2u) | ((HB >> 13) & 4u) | ((HB >> 28) & 8u);
         if (done) cand = 0;
         while (cand) {                                        // rare, divergent, exact
             const int k = __ffs(cand) - 1;
             cand &= cand - 1;
-            const uint2 pl = (k & 2) ? pb : pa;
+            const uint32_t ph = (k & 2) ? pl4.z : pl4.x, plo = (k & 2) ? pl4.w : pl4.y;
             const uint32_t sh = (k & 1) ? 16u : 0u;
-            const int idx = 2 * p + k;
+            const int idx = 4 * q + k;
             int ed, end;
-            exact_pair<K>((pl.x >> sh) & 0xFFFFu, (pl.y >> sh) & 0xFFFFu, XH, XL, len, tie, ed, end);
+            exact_pair<K>((ph >> sh) & 0xFFFFu, (plo >> sh) & 0xFFFFu, XH, XL, len, tie, ed, end);
             if (ed <= K && idx < n_wl) fold_update(ed, end, idx, best, hit, hit_end, done);
         }
     }

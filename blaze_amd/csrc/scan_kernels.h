@@ -391,31 +391,31 @@ __global__ void k_histogram(const int32_t *__restrict__ hit, int n, int n_wl, un
     }
 }
 
-// Integer-VALU ceiling probe: 8 independent chains of the scan kernel's own op mix.
+// Integer-VALU ceiling probe: 8 independent chains of the scan kernel's own full-rate op mix
+// (v_bitop3_b32 / v_add_u32 / v_xor_b32, all-VGPR operands), written in asm so that the
+// instruction count is exact: 32 VALU instructions per loop iteration.
 __global__ __launch_bounds__(256) void k_valu_probe(uint32_t *out, int iters, uint32_t seed) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t a[8];
+    uint32_t r[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] = tid * 2654435761u + k * 40503u + seed;
-    uint32_t b = ~tid ^ seed, c = tid * 97u + 13u, d = (tid << 7) ^ 0x5bd1e995u;
+    for (int k = 0; k < 8; ++k) r[k] = tid * 2654435761u + k * 40503u + seed;
+    uint32_t b = ~tid ^ seed, c = tid * 97u + 13u;
+#define BZ_P4(k)                                              \
+    "v_bitop3_b32 %" #k ", %" #k ", %8, %9 bitop3:0xa8\n"      \
+    "v_add_u32 %" #k ", %" #k ", %" #k "\n"                      \
+    "v_xor_b32 %" #k ", %" #k ", %8\n"                          \
+    "v_bitop3_b32 %" #k ", %" #k ", %9, %8 bitop3:0x60\n"
     for (int i = 0; i < iters; ++i) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            uint32_t x = a[k];
-            x = (x & b) | c;          // v_and_or_b32
-            x = (x << 1) | d;         // v_lshl_or_b32
-            x = x ^ b;                // v_xor_b32
-            x = x | c | d;            // v_or3_b32  (kept data dependent by the xor above)
-            x = x & (b ^ (uint32_t)i);// v_xor + v_and
-            a[k] = x ^ (uint32_t)k;   // v_xor
-        }
-        b += 0x9e3779b9u;             // v_add
+        asm volatile(BZ_P4(0) BZ_P4(1) BZ_P4(2) BZ_P4(3) BZ_P4(4) BZ_P4(5) BZ_P4(6) BZ_P4(7)
+                     : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                     : "v"(b), "v"(c));
     }
+#undef BZ_P4
     uint32_t s = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s ^= a[k];
+    for (int k = 0; k < 8; ++k) s ^= r[k];
     out[tid] = s;
 }
-constexpr int kProbeOpsPerIter = 8 * 7 + 1;
+constexpr int kProbeOpsPerIter = 32;
 
 }  // namespace bz

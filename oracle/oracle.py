@@ -100,8 +100,8 @@ def sub_edit_distance_bruteforce(a: str, b: str):
         return prev[len(y)]
 
     best, ends = len(p), {-1}
-    for e in range(len(t)):            # inclusive end
-        for s in range(e + 1):
+    for e in range(len(t)):            # inclusive end; s = e+1 is the empty substring "ending" at e
+        for s in range(e + 2):
             d = lev(p, t[s:e + 1])
             if d < best:
                 best, ends = d, {e}

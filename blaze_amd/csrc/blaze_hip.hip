@@ -91,12 +91,16 @@ struct Slot {
 
 struct bz_engine {
     int device = 0;
-    int tie_rule = 0, shortcut = 1, force_generic = 0;
+    int tie_rule = 0, shortcut = 1, force_generic = 0, scan_mode = 0;
     // whitelist
     int64_t n_wl = -1;
     int wl_regular = 0;
     int n_pairs = 0;
     uint2 *d_planes = nullptr;
+    uint4 *d_grams = nullptr;          // 3-gram sets, two barcodes per uint4, padded to 32 barcodes
+    uint32_t *d_planes32 = nullptr;    // hi-plane | lo-plane << 16 per barcode (verify gather)
+    int32_t *d_bucket = nullptr;       // bucket table over the sorted codes' top bits
+    int bucket_bits = 0, n_blk = 0;
     uint32_t *d_sorted_codes = nullptr;
     int32_t *d_sorted_idx = nullptr;
     uint8_t *d_wl_bytes = nullptr;
@@ -122,6 +126,8 @@ int use(bz_handle h) {
 void free_whitelist(bz_handle h) {
     hipFree(h->d_planes); hipFree(h->d_sorted_codes); hipFree(h->d_sorted_idx);
     hipFree(h->d_wl_bytes); hipFree(h->d_wl_off); hipFree(h->d_counts);
+    hipFree(h->d_grams); hipFree(h->d_planes32); hipFree(h->d_bucket);
+    h->d_grams = nullptr; h->d_planes32 = nullptr; h->d_bucket = nullptr;
     h->d_planes = nullptr; h->d_sorted_codes = nullptr; h->d_sorted_idx = nullptr;
     h->d_wl_bytes = nullptr; h->d_wl_off = nullptr; h->d_counts = nullptr;
     h->n_wl = -1;
@@ -168,6 +174,23 @@ void launch_scan(bz_handle h, Slot &s) {
     hipLaunchKernelGGL(bz::k_scan_bitparallel<K>, dim3(grid), dim3(block), 0, s.stream, (const uint4 *)h->d_planes, h->n_pairs, (int)h->n_wl,
                        s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
 }
+
+template <int K>
+void launch_scan_filtered(bz_handle h, Slot &s) {
+    const int block = 256;
+    const int grid = (int)((s.n + block - 1) / block);
+    hipLaunchKernelGGL(bz::k_scan_filtered<K>, dim3(grid), dim3(block), 0, s.stream, (const uint4 *)h->d_grams, h->d_planes32, h->n_blk,
+                       (int)h->n_wl, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+}
+
+// the striped totals behind counts[n_wl+2] -> counts[n_wl], counts[n_wl+1]
+int fold_totals(bz_handle h, hipStream_t st) {
+    hipLaunchKernelGGL(bz::k_fold_totals, dim3(1), dim3(64), 0, st, h->d_counts, (int)h->n_wl);
+    HIP_TRY(hipGetLastError());
+    return BZ_OK;
+}
+
+size_t counts_bytes(int64_t n_wl) { return (size_t)(n_wl + 2 + 2 * bz::kTotStripes) * sizeof(unsigned long long); }
 
 }  // namespace
 
@@ -237,6 +260,7 @@ int bz_set_option(bz_handle h, int option, int64_t value) {
         case BZ_OPT_TIE_RULE: if (value != 0 && value != 1) return fail(BZ_E_ARG, "tie rule must be 0 or 1"); h->tie_rule = (int)value; return BZ_OK;
         case BZ_OPT_SHORTCUT: h->shortcut = value ? 1 : 0; return BZ_OK;
         case BZ_OPT_FORCE_GENERIC: h->force_generic = value ? 1 : 0; return BZ_OK;
+        case BZ_OPT_SCAN_MODE: if (value != 0 && value != 1) return fail(BZ_E_ARG, "scan mode must be 0 or 1"); h->scan_mode = (int)value; return BZ_OK;
     }
     return fail(BZ_E_ARG, "unknown option %d", option);
 }
@@ -265,8 +289,8 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
     HIP_TRY(hipMalloc(&h->d_wl_off, (n + 1) * sizeof(int64_t)));
     if (total) HIP_TRY(hipMemcpy(h->d_wl_bytes, bytes + offsets[0], total, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->d_wl_off, off.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&h->d_counts, (n + 2) * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(h->d_counts, 0, (n + 2) * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&h->d_counts, counts_bytes(n)));
+    HIP_TRY(hipMemset(h->d_counts, 0, counts_bytes(n)));
 
     h->wl_regular = regular ? 1 : 0;
     h->n_pairs = 0;
@@ -303,6 +327,42 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
         HIP_TRY(hipMemcpy(h->d_sorted_codes, sorted.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->d_sorted_idx, idx.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
         h->n_pairs = (int)n_pairs;
+
+        // bucket table for the shortcut look-up: ~4 buckets per barcode, 2^8 .. 2^24 buckets
+        int bits = 8;
+        while (bits < 24 && ((int64_t)1 << bits) < 4 * n) ++bits;
+        const int64_t nb = (int64_t)1 << bits;
+        std::vector<int32_t> bucket(nb + 1);
+        {
+            int64_t k = 0;
+            for (int64_t b = 0; b <= nb; ++b) {
+                const uint64_t lim = (uint64_t)b << (32 - bits);     // first code of bucket b
+                while (k < n && (uint64_t)sorted[k] < lim) ++k;
+                bucket[b] = (int32_t)k;
+            }
+        }
+        HIP_TRY(hipMalloc(&h->d_bucket, (nb + 1) * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(h->d_bucket, bucket.data(), (nb + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+        h->bucket_bits = bits;
+
+        // filtered scan: 64-bit 3-gram set per barcode (padding = all ones: never passes), planes32
+        const int64_t n_blk = (n + bz::kFilterBlock - 1) / bz::kFilterBlock;
+        std::vector<uint2> grams(n_blk * bz::kFilterBlock, make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu));
+        std::vector<uint32_t> planes32(n);
+        for (int64_t k = 0; k < n; ++k) {
+            const uint32_t c = codes[k];
+            uint64_t set = 0;
+            for (int i = 0; i + 3 <= bz::kBcLen; ++i) set |= (uint64_t)1 << ((c >> (2 * i)) & 63u);
+            grams[k] = make_uint2((uint32_t)set, (uint32_t)(set >> 32));
+            uint32_t hi = 0, lo = 0;
+            for (int i = 0; i < bz::kBcLen; ++i) { hi |= ((c >> (2 * i + 1)) & 1u) << i; lo |= ((c >> (2 * i)) & 1u) << i; }
+            planes32[k] = hi | (lo << 16);
+        }
+        HIP_TRY(hipMalloc(&h->d_grams, grams.size() * sizeof(uint2)));
+        HIP_TRY(hipMalloc(&h->d_planes32, n * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(h->d_grams, grams.data(), grams.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->d_planes32, planes32.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        h->n_blk = (int)n_blk;
     }
     h->n_wl = n;
     return BZ_OK;
@@ -349,16 +409,19 @@ int bz_assign_run(bz_handle h, int slot, int max_ed) {
     HIP_TRY(hipMemsetAsync(s.d_counters, 0, 2 * sizeof(int32_t), s.stream));
     if (n) {
         hipLaunchKernelGGL(bz::k_classify, dim3((n + 255) / 256), dim3(256), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
-                           s.d_bcl, n, h->wl_regular, h->d_sorted_codes, h->d_sorted_idx, (int)h->n_wl, h->shortcut,
+                           s.d_bcl, n, h->wl_regular, h->d_sorted_codes, h->d_sorted_idx, (int)h->n_wl, h->d_bucket, h->bucket_bits, h->shortcut,
                            h->force_generic, max_ed, s.d_fast, s.d_gen, s.d_counters, s.d_hit, s.d_ed, s.d_end, s.d_flags);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(s.ev[1], s.stream));
     if (n && h->wl_regular && !h->force_generic && max_ed <= bz::kMaxK) {
+        // product path: exact 3-gram filter + verify for max_ed <= 2 (at 3 the filter passes ~40 % of the
+        // pairs and the brute-force scan is the faster one); BZ_OPT_SCAN_MODE 1 forces brute force
+        const bool filtered = h->scan_mode == 0 && max_ed <= 2;
         switch (max_ed) {
-            case 0: launch_scan<0>(h, s); break;
-            case 1: launch_scan<1>(h, s); break;
-            case 2: launch_scan<2>(h, s); break;
+            case 0: if (filtered) launch_scan_filtered<0>(h, s); else launch_scan<0>(h, s); break;
+            case 1: if (filtered) launch_scan_filtered<1>(h, s); else launch_scan<1>(h, s); break;
+            case 2: if (filtered) launch_scan_filtered<2>(h, s); else launch_scan<2>(h, s); break;
             default: launch_scan<3>(h, s); break;
         }
         HIP_TRY(hipGetLastError());
@@ -372,7 +435,7 @@ int bz_assign_run(bz_handle h, int slot, int max_ed) {
     }
     HIP_TRY(hipEventRecord(s.ev[3], s.stream));
     if (n) {
-        hipLaunchKernelGGL(bz::k_histogram, dim3((n + 255) / 256), dim3(256), 0, s.stream, s.d_hit, n, (int)h->n_wl, h->d_counts);
+        hipLaunchKernelGGL(bz::k_histogram, dim3(std::min((n + 255) / 256, 1024)), dim3(256), 0, s.stream, s.d_hit, n, (int)h->n_wl, h->d_counts);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(s.h_counters, s.d_counters, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
@@ -480,7 +543,7 @@ int bz_counts_reset(bz_handle h) {
     if (int rc = use(h)) return rc;
     if (h->n_wl < 0) return fail(BZ_E_STATE, "no whitelist");
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemset(h->d_counts, 0, (h->n_wl + 2) * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->d_counts, 0, counts_bytes(h->n_wl)));
     return BZ_OK;
 }
 
@@ -489,6 +552,8 @@ int bz_counts_get(bz_handle h, int64_t *out, int64_t n_out) {
     if (h->n_wl < 0) return fail(BZ_E_STATE, "no whitelist");
     if (!out || n_out != h->n_wl + 2) return fail(BZ_E_ARG, "n_out must be n_whitelist + 2");
     HIP_TRY(hipDeviceSynchronize());
+    if (int rc = fold_totals(h, h->slot[0].stream)) return rc;
+    HIP_TRY(hipStreamSynchronize(h->slot[0].stream));
     HIP_TRY(hipMemcpy(out, h->d_counts, n_out * sizeof(int64_t), hipMemcpyDeviceToHost));
     return BZ_OK;
 }
@@ -519,6 +584,7 @@ int bz_comm_allreduce_counts(bz_handle h) {
     if (h->n_wl < 0) return fail(BZ_E_STATE, "no whitelist");
     HIP_TRY(hipDeviceSynchronize());
     hipStream_t st = h->slot[0].stream;
+    if (int rc = fold_totals(h, st)) return rc;
     int r = g_rccl.AllReduce(h->d_counts, h->d_counts, (size_t)h->n_wl + 2, kNcclInt64, kNcclSum, h->comm, st);
     if (r) return fail(BZ_E_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     HIP_TRY(hipStreamSynchronize(st));

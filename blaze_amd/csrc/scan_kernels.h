@@ -127,6 +127,12 @@ __device__ __forceinline__ uint32_t in_vgpr(uint32_t x) {        // pin a (unifo
     return x;
 }
 
+__device__ __forceinline__ uint32_t popc_add(uint32_t x, uint32_t acc) {   // popcount(x) + acc in ONE instruction
+    uint32_t d;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
+    return d;
+}
+
 // Packed k-error Shift-And in the "S = R + R" form: Q = S | ONE is never materialised, ONE rides
 // along as a bitop3 operand.  R[d]' = ((S[d]|ONE) & eq) | R[d-1] | S[d-1] | S[d-1]' | ONE.
 template <int K>
@@ -221,6 +227,150 @@ __global__ __launch_bounds__(256) void k_scan_bitparallel(
             int ed, end;
             exact_pair<K>((ph >> sh) & 0xFFFFu, (plo >> sh) & 0xFFFFu, XH, XL, len, tie, ed, end);
             if (ed <= K && idx < n_wl) fold_update(ed, end, idx, best, hit, hit_end, done);
+        }
+    }
+    if (active) {
+        hit_out[r] = hit >= 0 ? hit : -1;
+        ed_out[r] = (int8_t)best;
+        end_out[r] = (int8_t)(hit >= 0 ? hit_end : -1);
+        flags_out[r] = (uint8_t)(hit == kHitAmbiguous ? kFlagAmbig : 0u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Filtered scan (the product path for max_ed <= 2): an EXACT q-gram pre-filter in front of the
+// same packed automaton.
+//
+// Lemma (Jokinen & Ukkonen 1991, for approximate substring matching): if the 16-nt barcode P
+// occurs in the text T with e <= K edit operations, every operation spoils at most 3 of P's 14
+// 3-gram positions, so at least 14-3K of them occur verbatim in T.  Hence the number of DISTINCT
+// 3-grams of P that are absent from T is <= 3K.  With the 64 possible 3-grams as one 64-bit set
+// per barcode (W, wave-uniform) and per read (E, per lane):   popcount(W & ~E) <= 3K
+// is necessary for sub_edit_distance(P, T) <= K.  Pairs that fail it can never enter the
+// reference's fold (read_assignment.py:73-85 ignores ed > best_ed), so skipping them is exact.
+// For uniform 16-mers ~2.3 % of the pairs pass at K = 2.
+//
+// Structure per lane (= one read), no cross-lane traffic, no barriers:
+//   filter : 32 barcodes per block, 2 v_and + 2 v_bcnt + 1 v_alignbit per pair -> a 32-bit pass
+//            mask (MSB = first barcode of the block);
+//   push   : mask bits -> barcode indices into the lane's own FIFO in LDS (whitelist order kept);
+//   verify : when some lane's FIFO is full (or the whitelist is exhausted) every lane pops two
+//            candidates, packs their planes into one register pair and runs the packed K-error
+//            automaton over the 20 text columns; accepting candidates take the rare exact path
+//            and the reference's order-dependent fold, in FIFO (= whitelist) order.
+constexpr int kQCap = 32;                                         // FIFO entries per lane (power of two)
+constexpr int kFilterBlock = 32;                                  // barcodes per filter block
+
+template <int K>
+__global__ __launch_bounds__(256) void k_scan_filtered(
+    const uint4 *__restrict__ grams, const uint32_t *__restrict__ planes32, int n_blk, int n_wl,
+    const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
+    const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int tie,
+    int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
+    __shared__ uint32_t fifo[kQCap][256];                         // [entry][thread]: bank = thread, conflict free
+    const int n_list = *n_list_ptr;
+    const int tid = threadIdx.x;
+    const int slot = blockIdx.x * blockDim.x + tid;
+    if ((slot & ~63) >= n_list) return;                           // whole wave idle (wave-uniform)
+    const bool active = slot < n_list;
+    const int r = list[active ? slot : n_list - 1];
+    const int len = ext_len[r];
+
+    uint32_t XH[kTextCols], XL[kTextCols];
+    uint32_t nelo = 0xFFFFFFFFu, nehi = 0xFFFFFFFFu;              // ~E: 3-grams NOT in the real text
+    {
+        const uint8_t *row = ext + (size_t)r * ext_stride;
+        uint32_t g = 0;
+#pragma unroll
+        for (int j = 0; j < kTextCols; ++j) {
+            const uint32_t c = (j < len) ? row[j] : (uint32_t)'A';
+            const uint32_t code = base_code(c);
+            XH[j] = (code & 2u) ? 0u : 0xFFFFFFFFu;
+            XL[j] = (code & 1u) ? 0u : 0xFFFFFFFFu;
+            g = (g >> 2) | (code << 4);                           // code[j-2] | code[j-1]<<2 | code[j]<<4
+            if (j >= 2 && j < len) {
+                if (g & 32u) nehi &= ~(1u << (g & 31u)); else nelo &= ~(1u << (g & 31u));
+            }
+        }
+    }
+    const uint32_t one = in_vgpr(kOne2);
+    const uint32_t thr = in_vgpr((uint32_t)(-(3 * K + 1)));       // diff = missing - (3K+1) < 0  <=>  pass
+
+    int best = K, hit = kHitNone, hit_end = -1;
+    bool done = !active;
+    uint32_t head = 0, tail = 0, mask = 0, base = 0;
+    int blk = 0;
+    constexpr int kFirst = kBcLen - K - 1;
+
+    for (;;) {
+        if (__builtin_amdgcn_ballot_w64(mask != 0) != 0) {
+            const bool full = mask != 0 && (tail - head) == (uint32_t)kQCap;
+            if (__builtin_amdgcn_ballot_w64(full) == 0) {         // push one candidate per lane
+                if (mask != 0) {
+                    const uint32_t b = (uint32_t)__builtin_clz(mask);
+                    mask &= ~(0x80000000u >> b);
+                    fifo[tail & (kQCap - 1)][tid] = base + b;
+                    ++tail;
+                }
+                continue;
+            }
+        } else if (blk < n_blk) {                                 // filter the next 32 barcodes
+            base = (uint32_t)blk * kFilterBlock;
+            uint32_t m = 0;
+            uint32_t goff = in_vgpr((uint32_t)blk * (kFilterBlock / 2) * (uint32_t)sizeof(uint4));   // wave-uniform, vector loads
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int i = 0; i < kFilterBlock / 4; ++i) {
+                    const uint4 w = *(const uint4 *)((const char *)grams + goff + i * sizeof(uint4));
+                    const uint32_t d0 = popc_add(w.y & nehi, popc_add(w.x & nelo, thr));
+                    const uint32_t d1 = popc_add(w.w & nehi, popc_add(w.z & nelo, thr));
+                    m = __builtin_amdgcn_alignbit(m, d0, 31);     // m = m << 1 | sign(d0)
+                    m = __builtin_amdgcn_alignbit(m, d1, 31);
+                }
+                goff += (kFilterBlock / 4) * (uint32_t)sizeof(uint4);
+            }
+            mask = done ? 0u : m;
+            ++blk;
+            continue;
+        } else if (__builtin_amdgcn_ballot_w64(tail != head) == 0) {
+            break;
+        }
+        // ---- verify round: pop up to two candidates per lane, oldest first
+        const uint32_t cnt = tail - head;
+        const bool have = cnt != 0;
+        uint32_t i0 = 0, i1 = 0;
+        if (have) {
+            i0 = fifo[head & (kQCap - 1)][tid];
+            i1 = cnt > 1 ? fifo[(head + 1) & (kQCap - 1)][tid] : i0;
+            head += cnt > 1 ? 2u : 1u;
+        }
+        const uint32_t p0 = planes32[i0], p1 = planes32[i1];
+        const uint32_t bh = (p0 & 0xFFFFu) | (p1 << 16), bl = (p0 >> 16) | (p1 & 0xFFFF0000u);
+        PackedScan<K> A;
+        A.init();
+        uint32_t H = 0, P = 0;
+#pragma unroll
+        for (int j = 0; j < kTextCols; ++j) {
+            const uint32_t eq = BZ_LUT3(bh ^ XH[j], bl, XL[j], kTA & (kTB ^ kTC));
+            if (j == kTextCols - 1) A.template step<true>(eq, one);
+            else A.template step<false>(eq, one);
+            if (j >= kFirst) {
+                if (((j - kFirst) & 1) == 0) P = A.R[K];
+                else H = BZ_LUT3(H, P, A.R[K], kTA | kTB | kTC);
+            }
+        }
+        if (((kTextCols - 1 - kFirst) & 1) == 0) H |= P;
+        uint32_t cand = ((H >> 15) & 1u) | ((H >> 30) & 2u);
+        if (!have || done) cand = 0;
+        if (cnt < 2) cand &= 1u;
+        while (cand) {                                            // rare, divergent, exact, in order
+            const int k = __ffs(cand) - 1;
+            cand &= cand - 1;
+            const uint32_t p = k ? p1 : p0;
+            int ed, end;
+            exact_pair<K>(p & 0xFFFFu, p >> 16, XH, XL, len, tie, ed, end);
+            if (ed <= K) fold_update(ed, end, (int)(k ? i1 : i0), best, hit, hit_end, done);
         }
     }
     if (active) {
@@ -341,54 +491,102 @@ __global__ void k_pair(const uint8_t *a, int la, const uint8_t *b, int lb, int m
 }
 
 // ------------------------------------------------------------------------------------------
-// Row classification + the exact-match shortcut (read_assignment.py:61-62) for regular rows:
-// binary search of the 2-bit code in the sorted whitelist (ties -> first index in caller order).
-__global__ void k_classify(const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
-                           const uint8_t *__restrict__ bc_off, const uint8_t *__restrict__ bc_len, int n, int wl_regular,
-                           const uint32_t *__restrict__ sorted_codes, const int32_t *__restrict__ sorted_idx, int n_wl,
-                           int shortcut, int force_generic, int max_ed, int32_t *__restrict__ fast_list,
-                           int32_t *__restrict__ gen_list, int32_t *__restrict__ counters, int32_t *__restrict__ hit_out,
-                           int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const int len = ext_len[r], off = bc_off[r], bl = bc_len[r];
-    hit_out[r] = -1; ed_out[r] = (int8_t)min(max_ed, 127); end_out[r] = -1;
-    if (bl == 0) { flags_out[r] = (uint8_t)kFlagBlank; return; }
-    flags_out[r] = 0;
-    const uint8_t *row = ext + (size_t)r * ext_stride;
-    bool regular = wl_regular && !force_generic && bl == kBcLen && len >= kBcLen && len <= kTextCols && max_ed <= kMaxK;
-    if (regular) {
-        bool ok = true;
-        for (int j = 0; j < len; ++j) ok = ok && is_acgt(row[j]);
-        regular = ok;
-    }
-    if (!regular) { gen_list[atomicAdd(&counters[1], 1)] = r; return; }
-    if (shortcut) {
-        uint32_t code = 0;
-#pragma unroll
-        for (int i = 0; i < kBcLen; ++i) code |= base_code(row[off + i]) << (2 * i);
-        int lo = 0, hi = n_wl;                                // lower bound
-        while (lo < hi) { int mid = (lo + hi) >> 1; if (sorted_codes[mid] < code) lo = mid + 1; else hi = mid; }
-        if (lo < n_wl && sorted_codes[lo] == code) {
-            hit_out[r] = sorted_idx[lo]; ed_out[r] = 0; flags_out[r] = (uint8_t)kFlagExact;
-            return;
-        }
-    }
-    fast_list[atomicAdd(&counters[0], 1)] = r;
-}
-
-// counts[hit] += 1 for assigned rows; counts[n_wl] += assigned, counts[n_wl+1] += rows.
-__global__ void k_histogram(const int32_t *__restrict__ hit, int n, int n_wl, unsigned long long *__restrict__ counts) {
+// Row classification + the exact-match shortcut (read_assignment.py:61-62) for regular rows.
+// `row.putative_bc in whitelist` = look-up of the 2-bit code in the sorted whitelist: a bucket table
+// over the code's top `bucket_bits` bits gives the (short) range, a lower-bound search inside it the
+// entry (duplicates -> first index in caller order).  2-3 dependent loads instead of log2(n_wl).
+__global__ __launch_bounds__(256) void k_classify(
+    const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
+    const uint8_t *__restrict__ bc_off, const uint8_t *__restrict__ bc_len, int n, int wl_regular,
+    const uint32_t *__restrict__ sorted_codes, const int32_t *__restrict__ sorted_idx, int n_wl,
+    const int32_t *__restrict__ bucket_start, int bucket_bits,
+    int shortcut, int force_generic, int max_ed, int32_t *__restrict__ fast_list,
+    int32_t *__restrict__ gen_list, int32_t *__restrict__ counters, int32_t *__restrict__ hit_out,
+    int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = r < n;
-    const int h = in ? hit[r] : -1;
-    if (h >= 0) atomicAdd(&counts[h], 1ull);
-    const unsigned long long m = __ballot(h >= 0);
-    const unsigned long long t = __ballot(in);
-    if ((threadIdx.x & 63) == 0) {
-        if (m) atomicAdd(&counts[n_wl], (unsigned long long)__popcll(m));
-        if (t) atomicAdd(&counts[n_wl + 1], (unsigned long long)__popcll(t));
+    const int len = in ? ext_len[r] : 0, off = in ? bc_off[r] : 0, bl = in ? bc_len[r] : 0;
+    int hit = -1;
+    uint32_t flags = 0;
+    int ed = min(max_ed, 127);
+    int route = 0;                                            // 0 none, 1 bit-parallel list, 2 generic list
+    if (bl == 0) {
+        flags = kFlagBlank;
+    } else {
+        const uint8_t *row = ext + (size_t)r * ext_stride;
+        bool regular = wl_regular && !force_generic && bl == kBcLen && len >= kBcLen && len <= kTextCols && max_ed <= kMaxK;
+        uint32_t code = 0;
+        if (regular) {
+            bool ok = true;
+            for (int j = 0; j < len; ++j) {
+                const uint32_t c = row[j];
+                ok = ok && is_acgt(c);
+                const int i = j - off;
+                if (i >= 0 && i < kBcLen) code |= base_code(c) << (2 * i);
+            }
+            regular = ok;
+        }
+        if (!regular) route = 2;
+        else {
+            route = 1;
+            if (shortcut) {
+                const uint32_t b = bucket_bits ? code >> (32 - bucket_bits) : 0u;
+                int lo = bucket_start[b], hi = bucket_start[b + 1];
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_codes[mid] < code) lo = mid + 1; else hi = mid; }
+                if (lo < n_wl && sorted_codes[lo] == code) { hit = sorted_idx[lo]; ed = 0; flags = kFlagExact; route = 0; }
+            }
+        }
     }
+    if (in) { hit_out[r] = hit; ed_out[r] = (int8_t)ed; end_out[r] = -1; flags_out[r] = (uint8_t)flags; }
+    // work-list compaction, one atomic per wave and list (every lane of the wave reaches this point)
+    const unsigned long long m1 = __builtin_amdgcn_ballot_w64(route == 1), m2 = __builtin_amdgcn_ballot_w64(route == 2);
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int base1 = 0, base2 = 0;
+    if (lane == 0) {
+        if (m1) base1 = atomicAdd(&counters[0], __popcll(m1));
+        if (m2) base2 = atomicAdd(&counters[1], __popcll(m2));
+    }
+    base1 = __shfl(base1, 0, 64);
+    base2 = __shfl(base2, 0, 64);
+    if (route == 1) fast_list[base1 + __popcll(m1 & below)] = r;
+    else if (route == 2) gen_list[base2 + __popcll(m2 & below)] = r;
+}
+
+// counts[hit] += 1 for assigned rows; the two totals (assigned, rows) go to kTotStripes striped
+// slots behind counts[n_wl + 2] (one atomic pair per workgroup, 16 per address per 1024-block
+// launch) and are folded into counts[n_wl], counts[n_wl+1] by k_fold_totals before anyone reads them.
+constexpr int kTotStripes = 64;
+__global__ __launch_bounds__(256) void k_histogram(const int32_t *__restrict__ hit, int n, int n_wl,
+                                                  unsigned long long *__restrict__ counts) {
+    __shared__ unsigned int s_assigned[4];
+    int assigned = 0;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const int h = hit[r];
+        if (h >= 0) { atomicAdd(&counts[h], 1ull); ++assigned; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) assigned += __shfl_down(assigned, o, 64);
+    if ((threadIdx.x & 63) == 0) s_assigned[threadIdx.x >> 6] = (unsigned int)assigned;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long a = (unsigned long long)s_assigned[0] + s_assigned[1] + s_assigned[2] + s_assigned[3];
+        const long long first = (long long)blockIdx.x * blockDim.x;
+        long long rows = 0;                                   // rows this block visited (grid-stride)
+        const long long step = (long long)gridDim.x * blockDim.x;
+        for (long long b = first; b < n; b += step) rows += min((long long)blockDim.x, (long long)n - b);
+        unsigned long long *tot = counts + n_wl + 2 + 2 * (blockIdx.x & (kTotStripes - 1));
+        if (a) atomicAdd(&tot[0], a);
+        if (rows) atomicAdd(&tot[1], (unsigned long long)rows);
+    }
+}
+
+__global__ void k_fold_totals(unsigned long long *__restrict__ counts, int n_wl) {
+    if (blockIdx.x != 0 || threadIdx.x >= 2) return;
+    unsigned long long s = 0;
+    unsigned long long *tot = counts + n_wl + 2;
+    for (int k = 0; k < kTotStripes; ++k) { s += tot[2 * k + threadIdx.x]; tot[2 * k + threadIdx.x] = 0; }
+    counts[n_wl + threadIdx.x] += s;
 }
 
 // Integer-VALU ceiling probe: 8 independent chains of the scan kernel's own full-rate op mix

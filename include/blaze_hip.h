@@ -49,6 +49,9 @@ typedef struct bz_engine *bz_handle;
 #define BZ_OPT_SHORTCUT 2      /* 1 (default) = exact-match shortcut of read_assignment.py:61-62;
                                   0 = score every non-blank row (benchmark "all rows scored" mode) */
 #define BZ_OPT_FORCE_GENERIC 3 /* 1 = send every row through the byte-wise DP kernel (testing) */
+#define BZ_OPT_SCAN_MODE 4     /* 0 (default) = exact 3-gram filter + verify for max_ed <= 2, brute force above;
+                                  1 = brute force always: every (row, barcode) pair runs the automaton
+                                  (the roofline leg of bench.py).  Results are identical in both modes. */
 
 /* result flags (per row) */
 #define BZ_F_EXACT 1u      /* took the exact-match shortcut */

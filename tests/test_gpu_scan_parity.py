@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 FLAG_MASK = _lib.BZ_F_EXACT | _lib.BZ_F_BLANK | _lib.BZ_F_AMBIG
 
 
-def _compare(engine, oracle, ext, el, bo, bl, wl, max_ed, tie=0, shortcut=True, force_generic=False, threads=8):
+def _compare(engine, oracle, ext, el, bo, bl, wl, max_ed, tie=0, shortcut=True, force_generic=False, threads=8,
+             scan_mode=0):
+    engine.set_option(_lib.BZ_OPT_SCAN_MODE, scan_mode)
     engine.set_option(_lib.BZ_OPT_TIE_RULE, tie)
     engine.set_option(_lib.BZ_OPT_SHORTCUT, int(shortcut))
     engine.set_option(_lib.BZ_OPT_FORCE_GENERIC, int(force_generic))
@@ -23,6 +25,7 @@ def _compare(engine, oracle, ext, el, bo, bl, wl, max_ed, tie=0, shortcut=True, 
     engine.set_option(_lib.BZ_OPT_TIE_RULE, 0)
     engine.set_option(_lib.BZ_OPT_SHORTCUT, 1)
     engine.set_option(_lib.BZ_OPT_FORCE_GENERIC, 0)
+    engine.set_option(_lib.BZ_OPT_SCAN_MODE, 0)
     bad = np.flatnonzero((hit != o_hit) | (ed != o_ed) | (end != o_end) | ((flags & FLAG_MASK) != o_flag))
     assert bad.size == 0, (
         f"{bad.size} rows differ, first {bad[0]}: ext={bytes(ext[bad[0], :el[bad[0]]])!r} "
@@ -39,22 +42,24 @@ def _synthetic(n_rows, n_cells, err=1.0, seed=3, umi_len=12):
     return rows, synth.codes_to_bytes(cells)
 
 
+@pytest.mark.parametrize("scan_mode", [0, 1], ids=["filtered", "bruteforce"])
 @pytest.mark.parametrize("max_ed", [0, 1, 2, 3])
 @pytest.mark.parametrize("tie", [0, 1])
-def test_bitparallel_vs_oracle(engine, oracle, max_ed, tie):
+def test_bitparallel_vs_oracle(engine, oracle, max_ed, tie, scan_mode):
     rows, wl = _synthetic(6000, 600, err=3.0, seed=100 + max_ed)
     ext, el, bo, bl = synth.pack_ext(rows)
     wl_list = [w.tobytes() for w in wl]
-    hit, ed, end, flags = _compare(engine, oracle, ext, el, bo, bl, wl_list, max_ed, tie)
+    hit, ed, end, flags = _compare(engine, oracle, ext, el, bo, bl, wl_list, max_ed, tie, scan_mode=scan_mode)
     t = engine.timing(0)
     assert t["rows_generic"] == 0 and t["rows_bitparallel"] > 0
     assert (hit >= 0).sum() > 1000
 
 
-def test_all_rows_scored_mode(engine, oracle):
+@pytest.mark.parametrize("scan_mode", [0, 1], ids=["filtered", "bruteforce"])
+def test_all_rows_scored_mode(engine, oracle, scan_mode):
     rows, wl = _synthetic(4000, 333, err=2.0, seed=7)        # odd whitelist size: exercises the padding
     ext, el, bo, bl = synth.pack_ext(rows)
-    _compare(engine, oracle, ext, el, bo, bl, [w.tobytes() for w in wl], 2, shortcut=False)
+    _compare(engine, oracle, ext, el, bo, bl, [w.tobytes() for w in wl], 2, shortcut=False, scan_mode=scan_mode)
     t = engine.timing(0)
     assert t["rows_bitparallel"] == int((bl > 0).sum())
 
@@ -152,8 +157,51 @@ def test_near_duplicate_whitelist_order_dependence(engine, oracle):
         np.random.default_rng(seed).shuffle(order)
         for tie in (0, 1):
             hit, *_ = _compare(engine, oracle, ext, el, bo, bl, order, 2, tie=tie)
+            hit_b, *_ = _compare(engine, oracle, ext, el, bo, bl, order, 2, tie=tie, scan_mode=1)
+            assert np.array_equal(hit, hit_b)
         outs.append(np.array([order[h] if h >= 0 else b"" for h in hit], dtype=object))
     assert any((outs[0] != outs[k]).any() for k in (1, 2)), "expected at least one order-dependent row"
+
+
+def test_low_complexity_whitelist_fills_the_candidate_fifo(engine, oracle):
+    """Homopolymer-rich barcodes have tiny 3-gram sets, so the filter passes almost every pair of a
+    low-complexity read: every lane's candidate FIFO overflows many times and drains mid-scan."""
+    rng = np.random.default_rng(31)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    wl = set()
+    while len(wl) < 700:
+        a, b = acgt[rng.integers(0, 4, 2)]
+        w = np.where(rng.random(16) < 0.85, a, b).astype(np.uint8)
+        for p in rng.choice(16, size=rng.integers(0, 2), replace=False):
+            w[p] = acgt[rng.integers(0, 4)]
+        wl.add(w.tobytes())
+    wl = list(wl)
+    n = 3000
+    ext = np.zeros((n, 32), dtype=np.uint8)
+    for r in range(n):
+        w = np.frombuffer(wl[rng.integers(0, len(wl))], dtype=np.uint8).copy()
+        for p in rng.choice(16, size=rng.integers(0, 4), replace=False):
+            w[p] = acgt[rng.integers(0, 4)]
+        ext[r, :20] = np.concatenate([acgt[rng.integers(0, 4, 2)], w, acgt[rng.integers(0, 4, 2)]])
+    el = np.full(n, 20, np.uint8); bo = np.full(n, 2, np.uint8); bl = np.full(n, 16, np.uint8)
+    for max_ed in (1, 2):
+        for shortcut in (True, False):
+            _compare(engine, oracle, ext, el, bo, bl, wl, max_ed, shortcut=shortcut)
+
+
+def test_filtered_equals_bruteforce_large(engine):
+    """BASELINE configs[2] shape (3v2 kit, 10-nt UMI, 20,000 cells) at a size the oracle would need
+    minutes for: the two device paths must agree on every row (and each is oracle-checked above)."""
+    rows, wl = _synthetic(120_000, 20_000, err=2.0, seed=41, umi_len=10)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    engine.set_whitelist_codes16(wl)
+    a = engine.assign(ext, el, bo, bl, 2)
+    engine.set_option(_lib.BZ_OPT_SCAN_MODE, 1)
+    b = engine.assign(ext, el, bo, bl, 2)
+    engine.set_option(_lib.BZ_OPT_SCAN_MODE, 0)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert (a[0] >= 0).sum() > 60_000
 
 
 def test_single_pair_entry_points(engine, oracle):

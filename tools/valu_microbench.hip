@@ -42,6 +42,21 @@
 #define I_AND_OR_E(k) "v_and_or_b32 %" #k ", %" #k ", %8, 1\n"
 #define I_XOR3(k) "v_xad_u32 %" #k ", %" #k ", %8, %9\n"
 #define I_MOV(k) "v_mov_b32 %" #k ", %8\n"
+#define I_BCNT(k) "v_bcnt_u32_b32 %" #k ", %8, %" #k "\n"
+#define I_ALIGNBIT(k) "v_alignbit_b32 %" #k ", %" #k ", %8, 31\n"
+#define I_ALIGNBIT_V(k) "v_alignbit_b32 %" #k ", %" #k ", %8, %9\n"
+#define I_CMP_ADDC(k) "v_cmp_le_u32 vcc, %" #k ", %8\n" "v_addc_co_u32 %" #k ", vcc, %" #k ", %" #k ", vcc\n"
+#define I_CMP(k) "v_cmp_le_u32 vcc, %" #k ", %8\n"
+#define I_CNDMASK(k) "v_cndmask_b32 %" #k ", %" #k ", %8, vcc\n"
+#define I_LSHR(k) "v_lshrrev_b32 %" #k ", 1, %" #k "\n"
+#define I_SUB(k) "v_sub_u32 %" #k ", %" #k ", %8\n"
+#define I_OR(k) "v_or_b32 %" #k ", %" #k ", %8\n"
+#define I_MIN(k) "v_min_u32 %" #k ", %" #k ", %8\n"
+#define I_PERM(k) "v_perm_b32 %" #k ", %" #k ", %8, %9\n"
+#define I_ANDN(k) "v_bitop3_b32 %" #k ", %" #k ", %8, %8 bitop3:0x30\n"
+#define I_ADD3(k) "v_add3_u32 %" #k ", %" #k ", %8, %9\n"
+#define I_LSHLADD(k) "v_lshl_add_u32 %" #k ", %" #k ", 1, %8\n"
+#define I_FILTER(k) "v_and_b32 %" #k ", %8, %" #k "\n" "v_bcnt_u32_b32 %" #k ", %" #k ", %9\n" "v_alignbit_b32 %" #k ", %8, %" #k ", 31\n"
 
 KERNEL(k_xor, REP8(I_XOR))
 KERNEL(k_xor_s, REP8(I_XOR_S))
@@ -61,6 +76,21 @@ KERNEL(k_fmac, REP8(I_FMAC))
 KERNEL(k_pk_add_u16, REP8(I_PKADD16))
 KERNEL(k_pk_lshl_b16, REP8(I_PKLSHL16))
 KERNEL(k_mov, REP8(I_MOV))
+KERNEL(k_bcnt, REP8(I_BCNT))
+KERNEL(k_alignbit, REP8(I_ALIGNBIT))
+KERNEL(k_alignbit_v, REP8(I_ALIGNBIT_V))
+KERNEL(k_cmp_addc, REP8(I_CMP_ADDC))
+KERNEL(k_cmp, REP8(I_CMP))
+KERNEL(k_cndmask, REP8(I_CNDMASK))
+KERNEL(k_lshr, REP8(I_LSHR))
+KERNEL(k_sub, REP8(I_SUB))
+KERNEL(k_or, REP8(I_OR))
+KERNEL(k_min, REP8(I_MIN))
+KERNEL(k_perm, REP8(I_PERM))
+KERNEL(k_andn, REP8(I_ANDN))
+KERNEL(k_add3, REP8(I_ADD3))
+KERNEL(k_lshladd, REP8(I_LSHLADD))
+KERNEL(k_filter, REP8(I_FILTER))
 // alternating VOP2 / VOP3
 #define I_MIX(k) "v_xor_b32 %" #k ", %" #k ", %8\n" "v_and_or_b32 %" #k ", %" #k ", %8, %9\n"
 KERNEL(k_mix_xor_andor, REP8(I_MIX))
@@ -78,13 +108,18 @@ int main() {
         {"v_or3_b32", k_or3, 8}, {"v_lshl_or_b32", k_lshl_or, 8}, {"v_bitop3_b32 3 vgpr", k_bitop3, 8},
         {"v_bitop3_b32 sgpr+2vgpr", k_bitop3_s, 8}, {"v_bitop3_b32 2 distinct vgpr", k_bitop3_2src, 8}, {"v_xad_u32", k_xad, 8},
         {"v_fma_f32", k_fma, 8}, {"v_fmac_f32 (VOP2)", k_fmac, 8}, {"v_pk_add_u16", k_pk_add_u16, 8},
-        {"v_pk_lshlrev_b16", k_pk_lshl_b16, 8}, {"v_mov_b32", k_mov, 8}, {"mix xor+and_or", k_mix_xor_andor, 16}};
+        {"v_pk_lshlrev_b16", k_pk_lshl_b16, 8}, {"v_mov_b32", k_mov, 8}, {"mix xor+and_or", k_mix_xor_andor, 16},
+        {"v_bcnt_u32_b32", k_bcnt, 8}, {"v_alignbit_b32 imm shift", k_alignbit, 8}, {"v_alignbit_b32 vgpr shift", k_alignbit_v, 8},
+        {"v_cmp_le_u32 + v_addc_co_u32", k_cmp_addc, 16}, {"v_cmp_le_u32 vcc", k_cmp, 8}, {"v_cndmask_b32 vcc", k_cndmask, 8},
+        {"v_lshrrev_b32", k_lshr, 8}, {"v_sub_u32", k_sub, 8}, {"v_or_b32", k_or, 8}, {"v_min_u32", k_min, 8},
+        {"v_perm_b32", k_perm, 8}, {"v_bitop3 andn 2src", k_andn, 8}, {"v_add3_u32", k_add3, 8}, {"v_lshl_add_u32", k_lshladd, 8},
+        {"filter mix and+bcnt+alignbit", k_filter, 24}};
     const int threads = 256, iters = 4000;
     uint32_t *d;
     hipMalloc(&d, (size_t)p.multiProcessorCount * 8 * threads * 4);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int bpc : {8, 4, 2, 1}) {           // blocks per CU: 8 -> 8 waves/SIMD ... 1 -> 1 wave/SIMD
+    for (int bpc : {8, 2}) {           // blocks per CU: 8 -> 8 waves/SIMD ... 1 -> 1 wave/SIMD
         printf("---- %d waves per SIMD ----\n", bpc);
         int blocks = p.multiProcessorCount * bpc;
         for (auto &c : cases) {

@@ -80,7 +80,7 @@ struct Slot {
     bool staged = false, ran = false;
     // device
     uint8_t *d_ext = nullptr, *d_len = nullptr, *d_off = nullptr, *d_bcl = nullptr, *d_flags = nullptr;
-    int32_t *d_hit = nullptr, *d_fast = nullptr, *d_gen = nullptr, *d_counters = nullptr;
+    int32_t *d_hit = nullptr, *d_fast = nullptr, *d_gen = nullptr, *d_redo = nullptr, *d_counters = nullptr;
     int8_t *d_ed = nullptr, *d_end = nullptr;
     // pinned host staging
     uint8_t *h_in = nullptr, *h_out = nullptr;
@@ -100,6 +100,8 @@ struct bz_engine {
     uint4 *d_grams = nullptr;          // 3-gram sets, two barcodes per uint4, padded to 32 barcodes
     uint32_t *d_planes32 = nullptr;    // hi-plane | lo-plane << 16 per barcode (verify gather)
     int32_t *d_bucket = nullptr;       // bucket table over the sorted codes' top bits
+    int32_t *d_seed_tab[2] = {nullptr, nullptr};      // seed index, plan 0: pieces 5|5|6 (max_ed 2), plan 1: 8|8 (max_ed <= 1)
+    int32_t *d_seed_members[2] = {nullptr, nullptr};  // per piece n_wl barcode indices grouped by the piece's code
     int bucket_bits = 0, n_blk = 0;
     uint32_t *d_sorted_codes = nullptr;
     int32_t *d_sorted_idx = nullptr;
@@ -128,6 +130,10 @@ void free_whitelist(bz_handle h) {
     hipFree(h->d_wl_bytes); hipFree(h->d_wl_off); hipFree(h->d_counts);
     hipFree(h->d_grams); hipFree(h->d_planes32); hipFree(h->d_bucket);
     h->d_grams = nullptr; h->d_planes32 = nullptr; h->d_bucket = nullptr;
+    for (int k = 0; k < 2; ++k) {
+        hipFree(h->d_seed_tab[k]); hipFree(h->d_seed_members[k]);
+        h->d_seed_tab[k] = nullptr; h->d_seed_members[k] = nullptr;
+    }
     h->d_planes = nullptr; h->d_sorted_codes = nullptr; h->d_sorted_idx = nullptr;
     h->d_wl_bytes = nullptr; h->d_wl_off = nullptr; h->d_counts = nullptr;
     h->n_wl = -1;
@@ -135,10 +141,10 @@ void free_whitelist(bz_handle h) {
 
 void free_slot(Slot &s) {
     hipFree(s.d_ext); hipFree(s.d_len); hipFree(s.d_off); hipFree(s.d_bcl); hipFree(s.d_flags);
-    hipFree(s.d_hit); hipFree(s.d_fast); hipFree(s.d_gen); hipFree(s.d_ed); hipFree(s.d_end);
+    hipFree(s.d_hit); hipFree(s.d_fast); hipFree(s.d_gen); hipFree(s.d_redo); hipFree(s.d_ed); hipFree(s.d_end);
     hipHostFree(s.h_in); hipHostFree(s.h_out);
     s.d_ext = s.d_len = s.d_off = s.d_bcl = s.d_flags = nullptr;
-    s.d_hit = s.d_fast = s.d_gen = nullptr;
+    s.d_hit = s.d_fast = s.d_gen = s.d_redo = nullptr;
     s.d_ed = s.d_end = nullptr;
     s.h_in = s.h_out = nullptr;
     s.cap = 0; s.cap_stride = 0;
@@ -155,6 +161,7 @@ int ensure_slot(Slot &s, int64_t n, int stride) {
     HIP_TRY(hipMalloc(&s.d_len, cap)); HIP_TRY(hipMalloc(&s.d_off, cap)); HIP_TRY(hipMalloc(&s.d_bcl, cap));
     HIP_TRY(hipMalloc(&s.d_flags, cap)); HIP_TRY(hipMalloc(&s.d_ed, cap)); HIP_TRY(hipMalloc(&s.d_end, cap));
     HIP_TRY(hipMalloc(&s.d_hit, cap * 4)); HIP_TRY(hipMalloc(&s.d_fast, cap * 4)); HIP_TRY(hipMalloc(&s.d_gen, cap * 4));
+    HIP_TRY(hipMalloc(&s.d_redo, cap * 4));
     HIP_TRY(hipHostMalloc(&s.h_in, (size_t)cap * (cs + 3), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(&s.h_out, (size_t)cap * 7, hipHostMallocDefault));
     s.cap = cap; s.cap_stride = cs;
@@ -181,6 +188,20 @@ void launch_scan_filtered(bz_handle h, Slot &s) {
     const int grid = (int)((s.n + block - 1) / block);
     hipLaunchKernelGGL(bz::k_scan_filtered<K>, dim3(grid), dim3(block), 0, s.stream, (const uint4 *)h->d_grams, h->d_planes32, h->n_blk,
                        (int)h->n_wl, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+}
+
+// seeded scan over fast_list; rows it could not fold (more than kMaxEvents near matches) go to
+// redo_list and are finished by the order-preserving filtered scan right behind it
+template <int K>
+void launch_scan_seeded(bz_handle h, Slot &s) {
+    const int block = 256;
+    const int grid = (int)((s.n + block - 1) / block);
+    const int plan = K == 2 ? 0 : 1;
+    hipLaunchKernelGGL(bz::k_scan_seeded<K>, dim3(grid), dim3(block), 0, s.stream, h->d_seed_tab[plan], h->d_seed_members[plan],
+                       h->d_planes32, (int)h->n_wl, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_redo,
+                       s.d_counters + 2, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+    hipLaunchKernelGGL(bz::k_scan_filtered<K>, dim3(grid), dim3(block), 0, s.stream, (const uint4 *)h->d_grams, h->d_planes32, h->n_blk,
+                       (int)h->n_wl, s.d_ext, s.stride, s.d_len, s.d_redo, s.d_counters + 2, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
 }
 
 // the striped totals behind counts[n_wl+2] -> counts[n_wl], counts[n_wl+1]
@@ -227,8 +248,8 @@ int bz_create(int device, bz_handle *out) {
     for (Slot &s : h->slot) {
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         for (hipEvent_t &e : s.ev) HIP_TRY(hipEventCreate(&e));
-        HIP_TRY(hipMalloc(&s.d_counters, 2 * sizeof(int32_t)));
-        HIP_TRY(hipHostMalloc(&s.h_counters, 2 * sizeof(int32_t), hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&s.d_counters, 4 * sizeof(int32_t)));
+        HIP_TRY(hipHostMalloc(&s.h_counters, 4 * sizeof(int32_t), hipHostMallocDefault));
     }
     HIP_TRY(hipMalloc(&h->d_pair, 4096));
     HIP_TRY(hipMalloc(&h->d_pair_out, 2 * sizeof(int32_t)));
@@ -260,7 +281,7 @@ int bz_set_option(bz_handle h, int option, int64_t value) {
         case BZ_OPT_TIE_RULE: if (value != 0 && value != 1) return fail(BZ_E_ARG, "tie rule must be 0 or 1"); h->tie_rule = (int)value; return BZ_OK;
         case BZ_OPT_SHORTCUT: h->shortcut = value ? 1 : 0; return BZ_OK;
         case BZ_OPT_FORCE_GENERIC: h->force_generic = value ? 1 : 0; return BZ_OK;
-        case BZ_OPT_SCAN_MODE: if (value != 0 && value != 1) return fail(BZ_E_ARG, "scan mode must be 0 or 1"); h->scan_mode = (int)value; return BZ_OK;
+        case BZ_OPT_SCAN_MODE: if (value < 0 || value > 2) return fail(BZ_E_ARG, "scan mode must be 0, 1 or 2"); h->scan_mode = (int)value; return BZ_OK;
     }
     return fail(BZ_E_ARG, "unknown option %d", option);
 }
@@ -363,6 +384,32 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
         HIP_TRY(hipMemcpy(h->d_grams, grams.data(), grams.size() * sizeof(uint2), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->d_planes32, planes32.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
         h->n_blk = (int)n_blk;
+
+        // seed index (k_scan_seeded): per piece a CSR bucket table over the piece's 2-bit code
+        const int plan_n[2] = {3, 2};
+        const int plan_len[2][3] = {{5, 5, 6}, {8, 8, 0}}, plan_off[2][3] = {{0, 5, 10}, {0, 8, 0}};
+        for (int pl = 0; pl < 2; ++pl) {
+            size_t tab_size = 0;
+            for (int q = 0; q < plan_n[pl]; ++q) tab_size += ((size_t)1 << (2 * plan_len[pl][q])) + 1;
+            std::vector<int32_t> tab(tab_size), mem((size_t)plan_n[pl] * n);
+            size_t base = 0;
+            for (int q = 0; q < plan_n[pl]; ++q) {
+                const size_t nb = (size_t)1 << (2 * plan_len[pl][q]);
+                const uint32_t mask = (uint32_t)(nb - 1);
+                int32_t *t = tab.data() + base;
+                std::fill(t, t + nb + 1, 0);
+                for (int64_t k = 0; k < n; ++k) ++t[((codes[k] >> (2 * plan_off[pl][q])) & mask) + 1];
+                for (size_t b = 0; b < nb; ++b) t[b + 1] += t[b];
+                std::vector<int32_t> fill(t, t + nb);
+                int32_t *m = mem.data() + (size_t)q * n;
+                for (int64_t k = 0; k < n; ++k) m[fill[(codes[k] >> (2 * plan_off[pl][q])) & mask]++] = (int32_t)k;
+                base += nb + 1;
+            }
+            HIP_TRY(hipMalloc(&h->d_seed_tab[pl], tab.size() * sizeof(int32_t)));
+            HIP_TRY(hipMalloc(&h->d_seed_members[pl], mem.size() * sizeof(int32_t)));
+            HIP_TRY(hipMemcpy(h->d_seed_tab[pl], tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(h->d_seed_members[pl], mem.data(), mem.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
     }
     h->n_wl = n;
     return BZ_OK;
@@ -406,7 +453,7 @@ int bz_assign_run(bz_handle h, int slot, int max_ed) {
     if (max_ed < 0 || max_ed > BZ_EXT_MAX) return fail(BZ_E_ARG, "max_ed %d outside 0..%d", max_ed, BZ_EXT_MAX);
     const int n = (int)s.n;
     HIP_TRY(hipEventRecord(s.ev[0], s.stream));
-    HIP_TRY(hipMemsetAsync(s.d_counters, 0, 2 * sizeof(int32_t), s.stream));
+    HIP_TRY(hipMemsetAsync(s.d_counters, 0, 4 * sizeof(int32_t), s.stream));
     if (n) {
         hipLaunchKernelGGL(bz::k_classify, dim3((n + 255) / 256), dim3(256), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
                            s.d_bcl, n, h->wl_regular, h->d_sorted_codes, h->d_sorted_idx, (int)h->n_wl, h->d_bucket, h->bucket_bits, h->shortcut,
@@ -415,13 +462,16 @@ int bz_assign_run(bz_handle h, int slot, int max_ed) {
     }
     HIP_TRY(hipEventRecord(s.ev[1], s.stream));
     if (n && h->wl_regular && !h->force_generic && max_ed <= bz::kMaxK) {
-        // product path: exact 3-gram filter + verify for max_ed <= 2 (at 3 the filter passes ~40 % of the
-        // pairs and the brute-force scan is the faster one); BZ_OPT_SCAN_MODE 1 forces brute force
-        const bool filtered = h->scan_mode == 0 && max_ed <= 2;
+        // product path for max_ed <= 2: pigeonhole seeds + verify (BZ_OPT_SCAN_MODE 0); mode 2 = exact 3-gram
+        // filter + verify over the whole whitelist; mode 1 = brute force (also what max_ed 3 takes: its
+        // seeds and 3-gram sets are too weak to pay)
+        // (event words hold the barcode index in 25 bits: larger whitelists take the filtered scan)
+        const bool seeded = h->scan_mode == 0 && max_ed <= 2 && h->n_wl < ((int64_t)1 << 25);
+        const bool filtered = !seeded && h->scan_mode != 1 && max_ed <= 2;
         switch (max_ed) {
-            case 0: if (filtered) launch_scan_filtered<0>(h, s); else launch_scan<0>(h, s); break;
-            case 1: if (filtered) launch_scan_filtered<1>(h, s); else launch_scan<1>(h, s); break;
-            case 2: if (filtered) launch_scan_filtered<2>(h, s); else launch_scan<2>(h, s); break;
+            case 0: if (seeded) launch_scan_seeded<0>(h, s); else if (filtered) launch_scan_filtered<0>(h, s); else launch_scan<0>(h, s); break;
+            case 1: if (seeded) launch_scan_seeded<1>(h, s); else if (filtered) launch_scan_filtered<1>(h, s); else launch_scan<1>(h, s); break;
+            case 2: if (seeded) launch_scan_seeded<2>(h, s); else if (filtered) launch_scan_filtered<2>(h, s); else launch_scan<2>(h, s); break;
             default: launch_scan<3>(h, s); break;
         }
         HIP_TRY(hipGetLastError());
@@ -438,7 +488,7 @@ int bz_assign_run(bz_handle h, int slot, int max_ed) {
         hipLaunchKernelGGL(bz::k_histogram, dim3(std::min((n + 255) / 256, 1024)), dim3(256), 0, s.stream, s.d_hit, n, (int)h->n_wl, h->d_counts);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipMemcpyAsync(s.h_counters, s.d_counters, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(hipMemcpyAsync(s.h_counters, s.d_counters, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(hipEventRecord(s.ev[4], s.stream));
     s.ran = true;
     return BZ_OK;
@@ -510,6 +560,7 @@ int bz_slot_timing(bz_handle h, int slot, float ms[8], int64_t counts[8]) {
     if (counts) {
         memset(counts, 0, 8 * sizeof(int64_t));
         counts[0] = s.n; counts[1] = s.h_counters[0]; counts[2] = s.h_counters[1]; counts[3] = h->n_wl;
+        counts[4] = s.h_counters[2];
     }
     return BZ_OK;
 }

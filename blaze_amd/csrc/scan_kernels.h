@@ -382,6 +382,190 @@ __global__ __launch_bounds__(256) void k_scan_filtered(
 }
 
 // ------------------------------------------------------------------------------------------
+// Seeded scan (the product path for max_ed <= 2): pigeonhole seeds + the same packed verify.
+//
+// Lemma (pigeonhole): cut the 16-nt barcode P into K+1 disjoint pieces.  An alignment of P inside
+// the text T with <= K edit operations leaves at least one piece untouched, and that piece then
+// occurs verbatim in T.  With s the start of the matched substring (0 <= s, the text has only
+// len-16+K spare columns) and d in [-K, K] the net indel shift in front of the piece, a piece at
+// barcode offset o starts at text column j = s + o + d; the loose window j in [o-2, o+6]
+// (clipped to the text) covers every case for len <= 20 and K <= 2.  So the set of barcodes that
+// share one piece with one of those <= 9 text windows is a SUPERSET of {w : sub_ed(w, T) <= K}; a
+// barcode outside it can never enter the reference's fold (read_assignment.py:73-85).
+//
+// Plan per K (SeedPlan): K = 2 -> pieces 5|5|6 nt (1024 / 1024 / 4096 buckets); K <= 1 -> 8|8 nt
+// (65536 buckets each; sound for K = 0 too).  The host builds, per piece, a bucket table over the
+// piece's 2-bit code (CSR: tab[code] .. tab[code+1] into `members`, barcode indices).  For a 5k
+// whitelist a read meets ~100 candidates instead of 5000 pairs.
+//
+// Per lane (= read): for each piece the 9 bucket ranges are looked up at once (independent
+// gathers, one latency), their members are streamed two per range per step into the lane's FIFO in
+// LDS, and whenever a lane's FIFO cannot take another step every lane pops two candidates and runs
+// the packed K-error automaton on them (same verify as k_scan_filtered).  Candidates arrive in
+// index order only within a bucket, so accepted ones (rare) are recorded as EVENTS (index, ed, end)
+// and the reference's order-dependent fold is replayed over the lane's events sorted by whitelist
+// index (duplicates dropped) at the end.  A lane with more than kMaxEvents events is not folded
+// here: its row goes to `redo_list` and the order-preserving k_scan_filtered finishes it.
+constexpr int kSeedShifts = 9;                                    // text windows per piece: o-2 .. o+6
+constexpr int kMaxEvents = 8;
+constexpr int kSeedBurst = 2 * kSeedShifts;                       // most FIFO pushes per step
+
+template <int K> struct SeedPlan;
+template <> struct SeedPlan<2> { static constexpr int n = 3; static constexpr int len[3] = {5, 5, 6}; static constexpr int off[3] = {0, 5, 10}; };
+template <> struct SeedPlan<1> { static constexpr int n = 2; static constexpr int len[3] = {8, 8, 0}; static constexpr int off[3] = {0, 8, 0}; };
+template <> struct SeedPlan<0> : SeedPlan<1> {};
+
+template <int K>
+__global__ __launch_bounds__(256) void k_scan_seeded(
+    const int32_t *__restrict__ tab, const int32_t *__restrict__ members, const uint32_t *__restrict__ planes32, int n_wl,
+    const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
+    const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int tie,
+    int32_t *__restrict__ redo_list, int32_t *__restrict__ n_redo,
+    int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
+    using Plan = SeedPlan<K>;
+    __shared__ uint32_t fifo[kQCap][256];
+    __shared__ uint32_t events[kMaxEvents][256];
+    const int n_list = *n_list_ptr;
+    const int tid = threadIdx.x;
+    const int slot = blockIdx.x * blockDim.x + tid;
+    if ((slot & ~63) >= n_list) return;                           // whole wave idle (wave-uniform)
+    const bool active = slot < n_list;
+    const int r = list[active ? slot : n_list - 1];
+    const int len = ext_len[r];
+
+    uint32_t XH[kTextCols], XL[kTextCols];
+    uint64_t tc = 0;                                              // 2-bit codes of the text, column j at bits 2j
+    {
+        const uint8_t *row = ext + (size_t)r * ext_stride;
+#pragma unroll
+        for (int j = 0; j < kTextCols; ++j) {
+            const uint32_t c = (j < len) ? row[j] : (uint32_t)'A';
+            const uint32_t code = base_code(c);
+            XH[j] = (code & 2u) ? 0u : 0xFFFFFFFFu;
+            XL[j] = (code & 1u) ? 0u : 0xFFFFFFFFu;
+            tc |= (uint64_t)code << (2 * j);
+        }
+    }
+    const uint32_t one = in_vgpr(kOne2);
+    uint32_t head = 0, tail = 0;
+    int nev = 0;
+    bool overflow = false;
+    constexpr int kFirst = kBcLen - K - 1;
+
+    // one verify round: every lane pops up to two candidates (oldest first) and runs the packed automaton
+    auto verify_round = [&]() {
+        const uint32_t cnt = tail - head;
+        const bool have = cnt != 0;
+        uint32_t i0 = 0, i1 = 0;
+        if (have) {
+            i0 = fifo[head & (kQCap - 1)][tid];
+            i1 = cnt > 1 ? fifo[(head + 1) & (kQCap - 1)][tid] : i0;
+            head += cnt > 1 ? 2u : 1u;
+        }
+        const uint32_t p0 = planes32[i0], p1 = planes32[i1];
+        const uint32_t bh = (p0 & 0xFFFFu) | (p1 << 16), bl = (p0 >> 16) | (p1 & 0xFFFF0000u);
+        PackedScan<K> A;
+        A.init();
+        uint32_t H = 0, P = 0;
+#pragma unroll
+        for (int j = 0; j < kTextCols; ++j) {
+            const uint32_t eq = BZ_LUT3(bh ^ XH[j], bl, XL[j], kTA & (kTB ^ kTC));
+            if (j == kTextCols - 1) A.template step<true>(eq, one);
+            else A.template step<false>(eq, one);
+            if (j >= kFirst) {
+                if (((j - kFirst) & 1) == 0) P = A.R[K];
+                else H = BZ_LUT3(H, P, A.R[K], kTA | kTB | kTC);
+            }
+        }
+        if (((kTextCols - 1 - kFirst) & 1) == 0) H |= P;
+        uint32_t cand = ((H >> 15) & 1u) | ((H >> 30) & 2u);
+        if (!have || !active) cand = 0;
+        if (cnt < 2) cand &= 1u;
+        while (cand) {                                            // rare, divergent, exact
+            const int k = __ffs(cand) - 1;
+            cand &= cand - 1;
+            const uint32_t p = k ? p1 : p0;
+            int ed, end;
+            exact_pair<K>(p & 0xFFFFu, p >> 16, XH, XL, len, tie, ed, end);
+            if (ed <= K) {                                        // a barcode met through several seeds is recorded once
+                const uint32_t ev = ((k ? i1 : i0) << 7) | ((uint32_t)ed << 5) | (uint32_t)end;
+                bool seen = false;
+                for (int a = 0; a < nev; ++a) seen = seen || events[a][tid] == ev;
+                if (!seen) {
+                    if (nev < kMaxEvents) events[nev++][tid] = ev;
+                    else overflow = true;
+                }
+            }
+        }
+    };
+
+#pragma unroll 1
+    for (int p = 0; p < Plan::n; ++p) {
+        constexpr int kBase1 = (1 << (2 * Plan::len[0])) + 1, kBase2 = kBase1 + (1 << (2 * Plan::len[1])) + 1;
+        const int lp = p == 0 ? Plan::len[0] : p == 1 ? Plan::len[1] : Plan::len[2];
+        const int op = p == 0 ? Plan::off[0] : p == 1 ? Plan::off[1] : Plan::off[2];
+        const int32_t *tp = tab + (p == 0 ? 0 : p == 1 ? kBase1 : kBase2);
+        const int32_t *mp = members + (size_t)p * n_wl;
+        int cur[kSeedShifts], end[kSeedShifts];
+#pragma unroll
+        for (int d = 0; d < kSeedShifts; ++d) {                   // 9 windows, 18 independent gathers
+            const int j = op - 2 + d;
+            cur[d] = 0; end[d] = 0;
+            if (active && j >= 0 && j + lp <= len) {              // window inside the real text
+                const uint32_t code = (uint32_t)(tc >> (2 * j)) & ((1u << (2 * lp)) - 1u);
+                cur[d] = tp[code]; end[d] = tp[code + 1];
+            }
+        }
+        for (;;) {
+            bool any = false;
+#pragma unroll
+            for (int d = 0; d < kSeedShifts; ++d) any = any || cur[d] < end[d];
+            if (__builtin_amdgcn_ballot_w64(any) == 0) break;
+            while (__builtin_amdgcn_ballot_w64((tail - head) > (uint32_t)(kQCap - kSeedBurst)) != 0) verify_round();
+            int32_t m0[kSeedShifts], m1[kSeedShifts];
+#pragma unroll
+            for (int d = 0; d < kSeedShifts; ++d) {               // up to two members per range, all loads in flight
+                m0[d] = cur[d] < end[d] ? mp[cur[d]] : -1;
+                m1[d] = cur[d] + 1 < end[d] ? mp[cur[d] + 1] : -1;
+            }
+#pragma unroll
+            for (int d = 0; d < kSeedShifts; ++d) {
+                if (m0[d] >= 0) { fifo[tail & (kQCap - 1)][tid] = (uint32_t)m0[d]; ++tail; }
+                if (m1[d] >= 0) { fifo[tail & (kQCap - 1)][tid] = (uint32_t)m1[d]; ++tail; }
+                cur[d] += 2;
+            }
+        }
+    }
+    while (__builtin_amdgcn_ballot_w64(tail != head) != 0) verify_round();
+
+    if (!active) return;
+    if (overflow) {                                               // too many near matches: finish in whitelist order
+        redo_list[atomicAdd(n_redo, 1)] = r;
+        return;
+    }
+    // replay the reference's fold over the events in whitelist order (insertion sort, duplicates dropped)
+    for (int a = 1; a < nev; ++a) {
+        const uint32_t v = events[a][tid];
+        int b = a - 1;
+        while (b >= 0 && events[b][tid] > v) { events[b + 1][tid] = events[b][tid]; --b; }
+        events[b + 1][tid] = v;
+    }
+    int best = K, hit = kHitNone, hit_end = -1;
+    bool done = false;
+    uint32_t prev = 0xFFFFFFFFu;
+    for (int a = 0; a < nev; ++a) {
+        const uint32_t v = events[a][tid];
+        if (v == prev) continue;
+        prev = v;
+        fold_update((int)((v >> 5) & 3u), (int)(v & 31u), (int)(v >> 7), best, hit, hit_end, done);
+    }
+    hit_out[r] = hit >= 0 ? hit : -1;
+    ed_out[r] = (int8_t)best;
+    end_out[r] = (int8_t)(hit >= 0 ? hit_end : -1);
+    flags_out[r] = (uint8_t)(hit == kHitAmbiguous ? kFlagAmbig : 0u);
+}
+
+// ------------------------------------------------------------------------------------------
 // Generic byte-wise semi-global DP (any alphabet, any lengths; pattern = the shorter operand,
 // the first one when equal).  Used for irregular rows / whitelists, max_ed > kMaxK and the
 // single-pair entry points.  D[0][j] = 0, D[i][0] = i, answer = min_j D[m][j], end = j-1.

@@ -49,9 +49,11 @@ typedef struct bz_engine *bz_handle;
 #define BZ_OPT_SHORTCUT 2      /* 1 (default) = exact-match shortcut of read_assignment.py:61-62;
                                   0 = score every non-blank row (benchmark "all rows scored" mode) */
 #define BZ_OPT_FORCE_GENERIC 3 /* 1 = send every row through the byte-wise DP kernel (testing) */
-#define BZ_OPT_SCAN_MODE 4     /* 0 (default) = exact 3-gram filter + verify for max_ed <= 2, brute force above;
+#define BZ_OPT_SCAN_MODE 4     /* 0 (default) = pigeonhole seeds + verify for max_ed <= 2, brute force above;
                                   1 = brute force always: every (row, barcode) pair runs the automaton
-                                  (the roofline leg of bench.py).  Results are identical in both modes. */
+                                  (the roofline leg of bench.py); 2 = exact 3-gram filter + verify over the
+                                  whole whitelist (also finishes the rows mode 0 hands on).
+                                  Results are identical in all modes. */
 
 /* result flags (per row) */
 #define BZ_F_EXACT 1u      /* took the exact-match shortcut */
@@ -102,7 +104,8 @@ int bz_assign_fetch(bz_handle h, int slot, int32_t *hit, int8_t *ed, int8_t *end
 int bz_slot_sync(bz_handle h, int slot);
 /* HIP-event durations (ms) of the slot's last run: ms[0] whole run, [1] classify+shortcut,
  * [2] bit-parallel scan, [3] generic scan, [4] histogram; counts[0] rows, [1] rows scored by the
- * bit-parallel kernel, [2] rows scored by the generic kernel, [3] whitelist size. */
+ * bit-parallel kernels, [2] rows scored by the generic kernel, [3] whitelist size, [4] rows the seeded
+ * scan handed to the filtered scan (more than 8 near matches). */
 int bz_slot_timing(bz_handle h, int slot, float ms[8], int64_t counts[8]);
 
 /* Single pair on the device: the drop-in for fast_edit_distance.sub_edit_distance(a, b, max_ed)

@@ -42,7 +42,7 @@ def _synthetic(n_rows, n_cells, err=1.0, seed=3, umi_len=12):
     return rows, synth.codes_to_bytes(cells)
 
 
-@pytest.mark.parametrize("scan_mode", [0, 1], ids=["filtered", "bruteforce"])
+@pytest.mark.parametrize("scan_mode", [0, 1, 2], ids=["seeded", "bruteforce", "filtered"])
 @pytest.mark.parametrize("max_ed", [0, 1, 2, 3])
 @pytest.mark.parametrize("tie", [0, 1])
 def test_bitparallel_vs_oracle(engine, oracle, max_ed, tie, scan_mode):
@@ -55,7 +55,7 @@ def test_bitparallel_vs_oracle(engine, oracle, max_ed, tie, scan_mode):
     assert (hit >= 0).sum() > 1000
 
 
-@pytest.mark.parametrize("scan_mode", [0, 1], ids=["filtered", "bruteforce"])
+@pytest.mark.parametrize("scan_mode", [0, 1, 2], ids=["seeded", "bruteforce", "filtered"])
 def test_all_rows_scored_mode(engine, oracle, scan_mode):
     rows, wl = _synthetic(4000, 333, err=2.0, seed=7)        # odd whitelist size: exercises the padding
     ext, el, bo, bl = synth.pack_ext(rows)
@@ -157,8 +157,10 @@ def test_near_duplicate_whitelist_order_dependence(engine, oracle):
         np.random.default_rng(seed).shuffle(order)
         for tie in (0, 1):
             hit, *_ = _compare(engine, oracle, ext, el, bo, bl, order, 2, tie=tie)
-            hit_b, *_ = _compare(engine, oracle, ext, el, bo, bl, order, 2, tie=tie, scan_mode=1)
-            assert np.array_equal(hit, hit_b)
+            for mode in (1, 2):
+                hit_b, *_ = _compare(engine, oracle, ext, el, bo, bl, order, 2, tie=tie, scan_mode=mode)
+                assert np.array_equal(hit, hit_b)
+        assert engine.timing(0)["rows_redo"] >= 0
         outs.append(np.array([order[h] if h >= 0 else b"" for h in hit], dtype=object))
     assert any((outs[0] != outs[k]).any() for k in (1, 2)), "expected at least one order-dependent row"
 
@@ -184,23 +186,29 @@ def test_low_complexity_whitelist_fills_the_candidate_fifo(engine, oracle):
             w[p] = acgt[rng.integers(0, 4)]
         ext[r, :20] = np.concatenate([acgt[rng.integers(0, 4, 2)], w, acgt[rng.integers(0, 4, 2)]])
     el = np.full(n, 20, np.uint8); bo = np.full(n, 2, np.uint8); bl = np.full(n, 16, np.uint8)
+    redo = 0
     for max_ed in (1, 2):
         for shortcut in (True, False):
-            _compare(engine, oracle, ext, el, bo, bl, wl, max_ed, shortcut=shortcut)
+            for mode in (0, 2):
+                _compare(engine, oracle, ext, el, bo, bl, wl, max_ed, shortcut=shortcut, scan_mode=mode)
+                if mode == 0:
+                    redo += engine.timing(0)["rows_redo"]
+    assert redo > 0, "expected rows with more than 8 near matches (seeded scan hands them to the filtered scan)"
 
 
-def test_filtered_equals_bruteforce_large(engine):
+def test_seeded_filtered_bruteforce_agree_large(engine):
     """BASELINE configs[2] shape (3v2 kit, 10-nt UMI, 20,000 cells) at a size the oracle would need
     minutes for: the two device paths must agree on every row (and each is oracle-checked above)."""
     rows, wl = _synthetic(120_000, 20_000, err=2.0, seed=41, umi_len=10)
     ext, el, bo, bl = synth.pack_ext(rows)
     engine.set_whitelist_codes16(wl)
     a = engine.assign(ext, el, bo, bl, 2)
-    engine.set_option(_lib.BZ_OPT_SCAN_MODE, 1)
-    b = engine.assign(ext, el, bo, bl, 2)
-    engine.set_option(_lib.BZ_OPT_SCAN_MODE, 0)
-    for x, y in zip(a, b):
-        assert np.array_equal(x, y)
+    for mode in (1, 2):
+        engine.set_option(_lib.BZ_OPT_SCAN_MODE, mode)
+        b = engine.assign(ext, el, bo, bl, 2)
+        engine.set_option(_lib.BZ_OPT_SCAN_MODE, 0)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
     assert (a[0] >= 0).sum() > 60_000
 
 

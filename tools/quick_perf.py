@@ -16,7 +16,7 @@ eng = Engine(0)
 ops, ms = eng.valu_peak_probe(20000)
 print(f"valu probe: {ops/1e12:.2f} T lane-ops/s ({ms:.2f} ms)")
 eng.set_whitelist_codes16(synth.codes_to_bytes(cells))
-for shortcut, mode in ((1, 0), (0, 0), (1, 1), (0, 1)):
+for shortcut, mode in ((1, 0), (0, 0), (1, 2), (0, 2), (1, 1), (0, 1)):
     eng.set_option(_lib.BZ_OPT_SHORTCUT, shortcut)
     eng.set_option(_lib.BZ_OPT_SCAN_MODE, mode)
     eng.stage(0, ext, el, bo, bl)
@@ -25,6 +25,6 @@ for shortcut, mode in ((1, 0), (0, 0), (1, 1), (0, 1)):
         t = eng.timing(0)
         pairs = t["rows_bitparallel"] * n_wl
         print(f"mode={mode} shortcut={shortcut} wall {wall*1e3:.2f} ms total {t['total_ms']:.2f} classify {t['classify_ms']:.3f} scan {t['scan_ms']:.2f} "
-              f"gen {t['generic_ms']:.3f} hist {t['hist_ms']:.3f} scored {t['rows_bitparallel']} "
+              f"gen {t['generic_ms']:.3f} hist {t['hist_ms']:.3f} scored {t['rows_bitparallel']} redo {t['rows_redo']} "
               f"-> {n_rows/ (t['total_ms']*1e-3)/1e6:.2f} M reads/s, {pairs/(t['scan_ms']*1e-3)/1e9:.1f} G pairs/s, "
               f"{pairs*340/(t['scan_ms']*1e-3)/1e12:.2f} T alg-ops/s")

@@ -455,7 +455,7 @@ int bz_assign_run(bz_handle h, int slot, int max_ed) {
     HIP_TRY(hipEventRecord(s.ev[0], s.stream));
     HIP_TRY(hipMemsetAsync(s.d_counters, 0, 4 * sizeof(int32_t), s.stream));
     if (n) {
-        hipLaunchKernelGGL(bz::k_classify, dim3((n + 255) / 256), dim3(256), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
+        hipLaunchKernelGGL(bz::k_classify, dim3((n + 256 * bz::kClassifyRows - 1) / (256 * bz::kClassifyRows)), dim3(256), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
                            s.d_bcl, n, h->wl_regular, h->d_sorted_codes, h->d_sorted_idx, (int)h->n_wl, h->d_bucket, h->bucket_bits, h->shortcut,
                            h->force_generic, max_ed, s.d_fast, s.d_gen, s.d_counters, s.d_hit, s.d_ed, s.d_end, s.d_flags);
         HIP_TRY(hipGetLastError());

@@ -41,6 +41,27 @@ constexpr unsigned kFlagExact = 1u, kFlagBlank = 2u, kFlagAmbig = 4u, kFlagGener
 __device__ __forceinline__ uint32_t base_code(uint32_t c) { return (c >> 1) & 3u; }   // A0 C1 T2 G3
 __device__ __forceinline__ bool is_acgt(uint32_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
 
+// First 20 bytes of a row as five little-endian words.  Rows of the packed layout (stride a multiple
+// of 16, >= 32, base 16-B aligned) take two 16-byte loads; anything else is read byte by byte.
+struct RowBytes {
+    uint32_t w[8];
+    __device__ __forceinline__ uint32_t at(int j) const { return (w[j >> 2] >> (8 * (j & 3))) & 0xFFu; }
+};
+__device__ __forceinline__ RowBytes load_row(const uint8_t *row, int stride) {
+    RowBytes b;
+    if ((stride & 15) == 0 && stride >= 32) {                 // wave-uniform
+        const uint4 lo = *(const uint4 *)row, hi = *(const uint4 *)(row + 16);
+        b.w[0] = lo.x; b.w[1] = lo.y; b.w[2] = lo.z; b.w[3] = lo.w;
+        b.w[4] = hi.x; b.w[5] = hi.y; b.w[6] = hi.z; b.w[7] = hi.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) b.w[k] = 0;
+        const int nb = stride < kTextCols ? stride : kTextCols;
+        for (int j = 0; j < nb; ++j) b.w[j >> 2] |= (uint32_t)row[j] << (8 * (j & 3));
+    }
+    return b;
+}
+
 // ------------------------------------------------------------------------------------------
 // k-error Shift-And state for one 32-bit word (two 16-bit automata when ONE = 0x00010001).
 // R[d] bit i  <=>  barcode[0..i] matches some suffix of the text read so far with <= d errors.
@@ -178,10 +199,10 @@ __global__ __launch_bounds__(256) void k_scan_bitparallel(
 
     // text bit-plane masks, inverted so that eq = (BH ^ XH) & (BL ^ XL)
     uint32_t XH[kTextCols], XL[kTextCols];
-    const uint8_t *row = ext + (size_t)r * ext_stride;
+    const RowBytes rb = load_row(ext + (size_t)r * ext_stride, ext_stride);
 #pragma unroll
     for (int j = 0; j < kTextCols; ++j) {
-        uint32_t c = (j < len) ? row[j] : (uint32_t)'A';     // columns past the text are padding
+        uint32_t c = (j < len) ? rb.at(j) : (uint32_t)'A';   // columns past the text are padding
         uint32_t code = base_code(c);
         XH[j] = (code & 2u) ? 0u : 0xFFFFFFFFu;
         XL[j] = (code & 1u) ? 0u : 0xFFFFFFFFu;
@@ -279,11 +300,11 @@ __global__ __launch_bounds__(256) void k_scan_filtered(
     uint32_t XH[kTextCols], XL[kTextCols];
     uint32_t nelo = 0xFFFFFFFFu, nehi = 0xFFFFFFFFu;              // ~E: 3-grams NOT in the real text
     {
-        const uint8_t *row = ext + (size_t)r * ext_stride;
+        const RowBytes rb = load_row(ext + (size_t)r * ext_stride, ext_stride);
         uint32_t g = 0;
 #pragma unroll
         for (int j = 0; j < kTextCols; ++j) {
-            const uint32_t c = (j < len) ? row[j] : (uint32_t)'A';
+            const uint32_t c = (j < len) ? rb.at(j) : (uint32_t)'A';
             const uint32_t code = base_code(c);
             XH[j] = (code & 2u) ? 0u : 0xFFFFFFFFu;
             XL[j] = (code & 1u) ? 0u : 0xFFFFFFFFu;
@@ -436,10 +457,10 @@ __global__ __launch_bounds__(256) void k_scan_seeded(
     uint32_t XH[kTextCols], XL[kTextCols];
     uint64_t tc = 0;                                              // 2-bit codes of the text, column j at bits 2j
     {
-        const uint8_t *row = ext + (size_t)r * ext_stride;
+        const RowBytes rb = load_row(ext + (size_t)r * ext_stride, ext_stride);
 #pragma unroll
         for (int j = 0; j < kTextCols; ++j) {
-            const uint32_t c = (j < len) ? row[j] : (uint32_t)'A';
+            const uint32_t c = (j < len) ? rb.at(j) : (uint32_t)'A';
             const uint32_t code = base_code(c);
             XH[j] = (code & 2u) ? 0u : 0xFFFFFFFFu;
             XL[j] = (code & 1u) ? 0u : 0xFFFFFFFFu;
@@ -679,6 +700,8 @@ __global__ void k_pair(const uint8_t *a, int la, const uint8_t *b, int lb, int m
 // `row.putative_bc in whitelist` = look-up of the 2-bit code in the sorted whitelist: a bucket table
 // over the code's top `bucket_bits` bits gives the (short) range, a lower-bound search inside it the
 // entry (duplicates -> first index in caller order).  2-3 dependent loads instead of log2(n_wl).
+constexpr int kClassifyRows = 4;                              // rows per thread: 1024 per workgroup, ONE list atomic pair per workgroup
+
 __global__ __launch_bounds__(256) void k_classify(
     const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
     const uint8_t *__restrict__ bc_off, const uint8_t *__restrict__ bc_len, int n, int wl_regular,
@@ -687,54 +710,69 @@ __global__ __launch_bounds__(256) void k_classify(
     int shortcut, int force_generic, int max_ed, int32_t *__restrict__ fast_list,
     int32_t *__restrict__ gen_list, int32_t *__restrict__ counters, int32_t *__restrict__ hit_out,
     int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = r < n;
-    const int len = in ? ext_len[r] : 0, off = in ? bc_off[r] : 0, bl = in ? bc_len[r] : 0;
-    int hit = -1;
-    uint32_t flags = 0;
-    int ed = min(max_ed, 127);
-    int route = 0;                                            // 0 none, 1 bit-parallel list, 2 generic list
-    if (bl == 0) {
-        flags = kFlagBlank;
-    } else {
-        const uint8_t *row = ext + (size_t)r * ext_stride;
-        bool regular = wl_regular && !force_generic && bl == kBcLen && len >= kBcLen && len <= kTextCols && max_ed <= kMaxK;
-        uint32_t code = 0;
-        if (regular) {
-            bool ok = true;
-            for (int j = 0; j < len; ++j) {
-                const uint32_t c = row[j];
-                ok = ok && is_acgt(c);
-                const int i = j - off;
-                if (i >= 0 && i < kBcLen) code |= base_code(c) << (2 * i);
-            }
-            regular = ok;
-        }
-        if (!regular) route = 2;
-        else {
-            route = 1;
-            if (shortcut) {
-                const uint32_t b = bucket_bits ? code >> (32 - bucket_bits) : 0u;
-                int lo = bucket_start[b], hi = bucket_start[b + 1];
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_codes[mid] < code) lo = mid + 1; else hi = mid; }
-                if (lo < n_wl && sorted_codes[lo] == code) { hit = sorted_idx[lo]; ed = 0; flags = kFlagExact; route = 0; }
-            }
-        }
-    }
-    if (in) { hit_out[r] = hit; ed_out[r] = (int8_t)ed; end_out[r] = -1; flags_out[r] = (uint8_t)flags; }
-    // work-list compaction, one atomic per wave and list (every lane of the wave reaches this point)
-    const unsigned long long m1 = __builtin_amdgcn_ballot_w64(route == 1), m2 = __builtin_amdgcn_ballot_w64(route == 2);
-    const unsigned lane = threadIdx.x & 63u;
+    __shared__ int s_cnt[2][kClassifyRows][4];                // [list][k][wave] -> exclusive offsets
+    __shared__ int s_base[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
-    int base1 = 0, base2 = 0;
-    if (lane == 0) {
-        if (m1) base1 = atomicAdd(&counters[0], __popcll(m1));
-        if (m2) base2 = atomicAdd(&counters[1], __popcll(m2));
+    int route[kClassifyRows];                                 // 0 none, 1 bit-parallel list, 2 generic list
+    int pos[kClassifyRows];                                   // rank inside (wave, k)
+#pragma unroll
+    for (int k = 0; k < kClassifyRows; ++k) {
+        const int r = (blockIdx.x * kClassifyRows + k) * 256 + threadIdx.x;
+        const bool in = r < n;
+        const int len = in ? ext_len[r] : 0, off = in ? bc_off[r] : 0, bl = in ? bc_len[r] : 0;
+        int hit = -1;
+        uint32_t flags = 0;
+        int ed = min(max_ed, 127);
+        int rt = 0;
+        if (bl == 0) {
+            flags = kFlagBlank;
+        } else {
+            bool regular = wl_regular && !force_generic && bl == kBcLen && len >= kBcLen && len <= kTextCols && max_ed <= kMaxK;
+            uint32_t code = 0;
+            if (regular) {
+                const RowBytes rb = load_row(ext + (size_t)r * ext_stride, ext_stride);
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < kTextCols; ++j) {
+                    const uint32_t c = rb.at(j);
+                    ok = ok && (j >= len || is_acgt(c));
+                    const int i = j - off;
+                    if (i >= 0 && i < kBcLen && j < len) code |= base_code(c) << (2 * i);
+                }
+                regular = ok;
+            }
+            if (!regular) rt = 2;
+            else {
+                rt = 1;
+                if (shortcut) {
+                    const uint32_t b = bucket_bits ? code >> (32 - bucket_bits) : 0u;
+                    int lo = bucket_start[b], hi = bucket_start[b + 1];
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_codes[mid] < code) lo = mid + 1; else hi = mid; }
+                    if (lo < n_wl && sorted_codes[lo] == code) { hit = sorted_idx[lo]; ed = 0; flags = kFlagExact; rt = 0; }
+                }
+            }
+        }
+        if (in) { hit_out[r] = hit; ed_out[r] = (int8_t)ed; end_out[r] = -1; flags_out[r] = (uint8_t)flags; }
+        const unsigned long long m1 = __builtin_amdgcn_ballot_w64(rt == 1), m2 = __builtin_amdgcn_ballot_w64(rt == 2);
+        route[k] = rt;
+        pos[k] = rt == 1 ? __popcll(m1 & below) : __popcll(m2 & below);
+        if (lane == 0) { s_cnt[0][k][wave] = __popcll(m1); s_cnt[1][k][wave] = __popcll(m2); }
     }
-    base1 = __shfl(base1, 0, 64);
-    base2 = __shfl(base2, 0, 64);
-    if (route == 1) fast_list[base1 + __popcll(m1 & below)] = r;
-    else if (route == 2) gen_list[base2 + __popcll(m2 & below)] = r;
+    __syncthreads();
+    if (threadIdx.x < 2) {                                    // one thread per list: exclusive scan of 16 counts, one atomic
+        int *c = &s_cnt[threadIdx.x][0][0];
+        int tot = 0;
+        for (int i = 0; i < kClassifyRows * 4; ++i) { const int v = c[i]; c[i] = tot; tot += v; }
+        s_base[threadIdx.x] = tot ? atomicAdd(&counters[threadIdx.x], tot) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kClassifyRows; ++k) {
+        const int r = (blockIdx.x * kClassifyRows + k) * 256 + threadIdx.x;
+        if (route[k] == 1) fast_list[s_base[0] + s_cnt[0][k][wave] + pos[k]] = r;
+        else if (route[k] == 2) gen_list[s_base[1] + s_cnt[1][k][wave] + pos[k]] = r;
+    }
 }
 
 // counts[hit] += 1 for assigned rows; the two totals (assigned, rows) go to kTotStripes striped

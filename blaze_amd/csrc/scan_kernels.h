@@ -6,23 +6,23 @@
 //
 // Design (CDNA4, wave64, integer VALU bound -- no MFMA, this is bit-vector work):
 //   * lane = read.  The read's <=20-nt extension lives in 40 VGPRs as per-column
-//     bit-plane masks (all-ones / all-zeros), constant over the whole whitelist scan.
+//     bit-plane masks (all-ones / all-zeros), constant over the whole scan.
 //   * the whitelist is packed 2 bits/base into two 16-bit planes per barcode and TWO
 //     barcodes share one 32-bit word per plane (low/high half) -> every VALU op scores two
-//     (read, barcode) pairs.  The planes are wave-uniform and are streamed through the
-//     scalar data path (s_load, read-only) so they cost no VGPRs and no vector issue slots.
-//   * per pair the kernel runs the k-error Shift-And automaton (Wu-Manber form of the
+//     (read, barcode) pairs.  Wave-uniform operands are fetched with vector loads into VGPRs:
+//     an SGPR source halves the issue rate of a VALU instruction on gfx950 (measured).
+//   * per pair the kernels run the k-error Shift-And automaton (Wu-Manber form of the
 //     Myers/Hyyro family: pure and/or/shift, no carries, so two 16-bit automata run in one
 //     32-bit register with no cross-talk: the only bit that leaks from the low half's shift
-//     lands on the high half's always-one bit).  Cost: 3 ops for the match mask + 2 + 3K ops
-//     per text column, for 2 pairs.  The automaton accepts iff the semi-global edit distance
-//     of the barcode inside the extension is <= K = max_ed.
+//     lands on the high half's always-one bit).  The automaton accepts iff the semi-global edit
+//     distance of the barcode inside the extension is <= K = max_ed.
 //   * accepting pairs are rare (~1 per read).  They take a divergent, exact path that
 //     re-runs the automaton un-packed, records the per-column distance, derives
-//     (ed, end_idx) under the configured tie rule and applies the reference's
-//     ORDER-DEPENDENT fold literally (ed<best / ed==best / 'ambiguous' / best-=1).
-//     Because each lane walks the whitelist in the caller's order, no cross-lane
-//     reduction is needed and the fold is exact by construction.
+//     (ed, end_idx) under the configured tie rule and feeds the reference's
+//     ORDER-DEPENDENT fold (ed<best / ed==best / 'ambiguous' / best-=1), always in whitelist order.
+//   * three scans share that core: k_scan_seeded (pigeonhole seeds pick the candidates, product
+//     path), k_scan_filtered (3-gram set filter over the whole whitelist, in order) and
+//     k_scan_bitparallel (every pair, the all-pairs roofline leg).  All give identical results.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -15,13 +15,14 @@ LIB_PATH = os.path.join(_HERE, "lib", "libblaze_hip.so")
 BZ_OPT_TIE_RULE, BZ_OPT_SHORTCUT, BZ_OPT_FORCE_GENERIC, BZ_OPT_SCAN_MODE = 1, 2, 3, 4
 BZ_F_EXACT, BZ_F_BLANK, BZ_F_AMBIG, BZ_F_GENERIC = 1, 2, 4, 8
 BZ_EXT_MAX = 64
+BZ_E_MISMATCH = -6
 
 EXPORTS = [
     "bz_abi_version", "bz_last_error", "bz_device_count", "bz_device_info", "bz_create", "bz_destroy",
     "bz_set_option", "bz_set_whitelist", "bz_assign_submit", "bz_assign_wait", "bz_assign_stage",
     "bz_assign_run", "bz_assign_fetch", "bz_slot_sync", "bz_slot_timing", "bz_sub_edit_distance",
     "bz_edit_distance", "bz_counts_reset", "bz_counts_get", "bz_comm_unique_id", "bz_comm_init",
-    "bz_comm_allreduce_counts", "bz_comm_allreduce_f64", "bz_comm_destroy", "bz_valu_peak_probe",
+    "bz_comm_allreduce_counts", "bz_comm_allreduce_f64", "bz_comm_destroy", "bz_valu_peak_probe", "bz_assign_files",
 ]
 
 
@@ -70,6 +71,7 @@ def load():
         "bz_comm_allreduce_f64": ([p, p, i, i], i),
         "bz_comm_destroy": ([p], i),
         "bz_valu_peak_probe": ([p, i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_float)], i),
+        "bz_assign_files": ([ctypes.POINTER(p), i, ctypes.POINTER(cp), i, cp, cp, i, i, i, i, i64, i, ctypes.POINTER(i64)], i),
     }
     for name, (args, res) in sig.items():
         fn = getattr(L, name)       # AttributeError if the .so lacks a declared symbol

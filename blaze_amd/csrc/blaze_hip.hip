@@ -10,12 +10,15 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
+#include <limits>
 #include <numeric>
 #include <string>
 #include <vector>
 
 #include "../../include/blaze_hip.h"
 #include "scan_kernels.h"
+#include "host_io.h"
 
 namespace {
 
@@ -109,6 +112,8 @@ struct bz_engine {
     int64_t *d_wl_off = nullptr;
     unsigned long long *d_counts = nullptr;
     Slot slot[BZ_SLOTS];
+    std::vector<char> wl_host;         // host copy of the whitelist (bz_assign_files writes barcodes from it)
+    std::vector<int64_t> wl_off_host;
     // single-pair scratch
     uint8_t *d_pair = nullptr;
     int32_t *d_pair_out = nullptr;
@@ -313,6 +318,8 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
     HIP_TRY(hipMalloc(&h->d_counts, counts_bytes(n)));
     HIP_TRY(hipMemset(h->d_counts, 0, counts_bytes(n)));
 
+    h->wl_host.assign(bytes + (n ? offsets[0] : 0), bytes + (n ? offsets[0] : 0) + total);
+    h->wl_off_host = off;
     h->wl_regular = regular ? 1 : 0;
     h->n_pairs = 0;
     if (regular) {
@@ -661,6 +668,127 @@ int bz_comm_destroy(bz_handle h) {
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     h->comm = nullptr;
     return BZ_OK;
+}
+
+// ---- whole step 3 over files (native host pipeline, host_io.h) ------------------------------------------------
+int bz_assign_files(bz_handle *engines, int n_engines, const char *const *fastq_fns, int n_fastq, const char *putative_bc_csv,
+                    const char *fastq_out, int gz, int restrand, int max_ed, int batch_size, int64_t device_batch_rows,
+                    int n_threads, int64_t out_counts[4]) {
+    if (!engines || n_engines < 1 || !fastq_fns || n_fastq < 0 || !putative_bc_csv || !fastq_out) return fail(BZ_E_ARG, "bad file arguments");
+    if (batch_size < 1 || device_batch_rows < 1 || n_threads < 1) return fail(BZ_E_ARG, "batch_size, device_batch_rows and n_threads must be >= 1");
+    for (int e = 0; e < n_engines; ++e) {
+        if (!engines[e]) return fail(BZ_E_ARG, "null engine");
+        if (engines[e]->n_wl < 0) return fail(BZ_E_STATE, "bz_set_whitelist has not been called on engine %d", e);
+    }
+    bzio::Job job;
+    for (int k = 0; k < n_fastq; ++k) job.fastq_fns.emplace_back(fastq_fns[k]);
+    job.csv = putative_bc_csv; job.out_path = fastq_out;
+    job.gz = gz != 0; job.restrand = restrand != 0; job.max_ed = max_ed; job.batch_size = batch_size;
+    job.n_threads = n_threads; job.device_batch_rows = std::min<int64_t>(device_batch_rows, (int64_t)1 << 24);
+
+    struct Queue {                                   // reader thread -> main thread, depth 2
+        std::mutex mu; std::condition_variable cv;
+        std::deque<std::unique_ptr<bzio::Chunk>> q;
+        bool done = false, stop = false;
+        std::exception_ptr err;
+    } Q;
+    std::thread reader;
+    std::deque<std::unique_ptr<bzio::Chunk>> inflight;
+    FILE *fo = nullptr;
+    int64_t demul_tot = 0, reads_tot = 0, n_chunks = 0;
+    int rc = BZ_OK;
+    auto shutdown = [&]() {
+        { std::lock_guard<std::mutex> g(Q.mu); Q.stop = true; }
+        Q.cv.notify_all();
+        if (reader.joinable()) reader.join();
+        for (auto &c : inflight) hipStreamSynchronize(engines[c->engine]->slot[c->slot].stream);
+        inflight.clear();
+        if (fo) { fclose(fo); fo = nullptr; }
+    };
+    try {
+        fo = fopen(fastq_out, "wb");
+        if (!fo) throw std::runtime_error(std::string("cannot open ") + fastq_out + " for writing");
+        reader = std::thread([&]() {
+            try {
+                bzio::ChunkReader rd(job);
+                for (;;) {
+                    auto ch = rd.next();
+                    std::unique_lock<std::mutex> lk(Q.mu);
+                    if (!ch) break;
+                    Q.cv.wait(lk, [&] { return Q.q.size() < 2 || Q.stop; });
+                    if (Q.stop) return;
+                    Q.q.push_back(std::move(ch));
+                    Q.cv.notify_all();
+                }
+            } catch (...) {
+                std::lock_guard<std::mutex> g(Q.mu);
+                Q.err = std::current_exception();
+            }
+            { std::lock_guard<std::mutex> g(Q.mu); Q.done = true; }
+            Q.cv.notify_all();
+        });
+        const bz_handle e0 = engines[0];
+        auto finish = [&](std::unique_ptr<bzio::Chunk> ch) {
+            const size_t n = ch->reads.size();
+            ch->hit.resize(n); ch->ed.resize(n); ch->end_idx.resize(n); ch->flags.resize(n);
+            if (bz_assign_wait(engines[ch->engine], ch->slot, ch->hit.data(), ch->ed.data(), ch->end_idx.data(), ch->flags.data()) != BZ_OK)
+                throw std::runtime_error(g_err);
+            const int nb = (int)ch->batch_start.size() - 1;
+            ch->out.resize(nb); ch->demul.assign(nb, 0);
+            bzio::Chunk &c = *ch;
+            bzio::parallel_for(nb, job.n_threads, [&](int b) { bzio::format_batch(c, b, job, e0->wl_host, e0->wl_off_host); });
+            for (int b = 0; b < nb; ++b) {
+                if (!c.out[b].empty() && fwrite(c.out[b].data(), 1, c.out[b].size(), fo) != c.out[b].size())
+                    throw std::runtime_error(std::string("write error on ") + fastq_out);
+                demul_tot += c.demul[b];
+            }
+            reads_tot += (int64_t)n;
+        };
+        for (int64_t k = 0;; ++k) {
+            std::unique_ptr<bzio::Chunk> ch;
+            {
+                std::unique_lock<std::mutex> lk(Q.mu);
+                Q.cv.wait(lk, [&] { return !Q.q.empty() || Q.done; });
+                if (Q.err) std::rethrow_exception(Q.err);
+                if (Q.q.empty()) break;
+                ch = std::move(Q.q.front());
+                Q.q.pop_front();
+            }
+            Q.cv.notify_all();
+            const size_t n = ch->reads.size();
+            ch->bc.resize(n); ch->umi.resize(n); ch->post.resize(n); ch->rid.resize(n); ch->polyT.resize(n);
+            ch->ext.resize(n * bzio::kExtStride); ch->ext_len.resize(n); ch->bc_off.resize(n); ch->bc_len.resize(n);
+            bzio::Chunk &c = *ch;
+            bzio::parallel_for((int)c.batch_start.size() - 1, job.n_threads, [&](int b) { bzio::parse_batch(c, b); });
+            if ((int)inflight.size() == 2 * n_engines) {
+                auto old = std::move(inflight.front());
+                inflight.pop_front();
+                finish(std::move(old));
+            }
+            c.engine = (int)(k % n_engines); c.slot = (int)((k / n_engines) % 2);
+            if (bz_assign_submit(engines[c.engine], c.slot, c.ext.data(), bzio::kExtStride, c.ext_len.data(), c.bc_off.data(),
+                                 c.bc_len.data(), (int64_t)n, max_ed) != BZ_OK)
+                throw std::runtime_error(g_err);
+            inflight.push_back(std::move(ch));
+            ++n_chunks;
+        }
+        while (!inflight.empty()) {
+            auto old = std::move(inflight.front());
+            inflight.pop_front();
+            finish(std::move(old));
+        }
+        if (fclose(fo) != 0) { fo = nullptr; throw std::runtime_error(std::string("write error on ") + fastq_out); }
+        fo = nullptr;
+    } catch (const bzio::MismatchError &e) {
+        rc = fail(BZ_E_MISMATCH, "%s", e.what());
+    } catch (const std::exception &e) {
+        rc = fail(BZ_E_ARG, "%s", e.what());
+    }
+    const std::string keep = g_err;
+    shutdown();
+    g_err = keep;
+    if (out_counts) { out_counts[0] = demul_tot; out_counts[1] = reads_tot; out_counts[2] = n_chunks; out_counts[3] = 0; }
+    return rc;
 }
 
 int bz_valu_peak_probe(bz_handle h, int iters, double *lane_ops_per_s, float *ms_out) {

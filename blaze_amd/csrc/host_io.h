@@ -1,0 +1,415 @@
+// host_io.h -- native host side of step 3 around the device scan: bz_assign_files().
+//
+// What it replaces (file:line under /root/reference/blaze):
+//   _read_and_bc_batch_generator_with_idx   read_assignment.py:138-181  lock-step FASTQ + putative_bc.csv batches
+//   helper.fastq_parser / batch_iterator     helper.py:275-301           4-line records, batches per input file
+//   _assign_read_batches, second loop        read_assignment.py:214-247  id check, trim, restrand, record, gzip member
+//   _match_bc_row epilogue                   read_assignment.py:51-62,87-99  strand, shortcut, UMI start correction
+//   assign_read's ordered byte concatenation read_assignment.py:293-327
+// The per-batch `pd.read_csv` of :160-164 is restated for the seven columns of main.py:96-105:
+//   * string cells: pandas' default NA tokens ('', 'NA', 'NaN', 'null', ... ) become NaN and `fillna('')` (:205) turns
+//     them into '' -- so a 2-nt flank spelled "NA" reads as empty in the reference, and does here;
+//   * polyT_end: float64/int64 in pandas, only truth-tested, sign-tested and int()-ed (:51-56, :227-232);
+//   * a batch whose read_id cells are ALL numeric is inferred as a numeric column by pandas and then fails the
+//     reference's `bc.read_id != r.id` check (:220) -- reproduced as the same "different order" error.
+// Files are read as bytes; Python's universal-newline translation is reproduced for "\r\n" (a lone '\r' as a line
+// terminator is not).  Output bytes equal the reference's for plain FASTQ; for .gz the DECOMPRESSED stream is equal and
+// the member boundaries are the reference's (one member per --batch-size reads per input file), the compressed bytes
+// themselves are not reproducible even in the reference (gzip header mtime).
+#pragma once
+#include <zlib.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <exception>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace bzio {
+
+struct Span { uint32_t off = 0, len = 0; };
+
+inline bool py_space(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x1f); }
+
+// ---- sequential line source over a plain or gzip file (zlib's gzread reads both) ------------------------------
+class LineReader {
+   public:
+    explicit LineReader(const std::string &path) : path_(path) {
+        f_ = gzopen(path.c_str(), "rb");
+        if (!f_) throw std::runtime_error("cannot open " + path);
+        gzbuffer(f_, 1 << 20);
+        buf_.resize(8 << 20);
+    }
+    ~LineReader() { if (f_) gzclose(f_); }
+    LineReader(const LineReader &) = delete;
+    // Next line without its terminator ("\n" or "\r\n") appended to `dst`; false at end of file.
+    bool next(std::vector<char> &dst, Span &out) {
+        out.off = (uint32_t)dst.size();
+        bool any = false;
+        for (;;) {
+            if (pos_ == end_) {
+                if (eof_) break;
+                int got = gzread(f_, buf_.data(), (unsigned)buf_.size());
+                if (got < 0) throw std::runtime_error("read error in " + path_);
+                if (got == 0) { eof_ = true; break; }
+                pos_ = 0; end_ = (size_t)got;
+            }
+            const char *p = buf_.data() + pos_;
+            const char *nl = (const char *)memchr(p, '\n', end_ - pos_);
+            any = true;
+            if (nl) {
+                dst.insert(dst.end(), p, nl);
+                pos_ = (size_t)(nl - buf_.data()) + 1;
+                if (dst.size() > out.off && dst.back() == '\r') dst.pop_back();
+                out.len = (uint32_t)(dst.size() - out.off);
+                return true;
+            }
+            dst.insert(dst.end(), p, (const char *)buf_.data() + end_);
+            pos_ = end_;
+        }
+        if (!any) return false;
+        out.len = (uint32_t)(dst.size() - out.off);      // last line without a newline
+        return true;
+    }
+
+   private:
+    std::string path_;
+    gzFile f_ = nullptr;
+    std::vector<char> buf_;
+    size_t pos_ = 0, end_ = 0;
+    bool eof_ = false;
+};
+
+// ---- one device batch worth of input ------------------------------------------------------------------------
+struct Read { Span id, seq, qual, csv; };
+struct Chunk {
+    std::vector<char> text;                  // all bytes the spans point into
+    std::vector<Read> reads;
+    std::vector<uint32_t> batch_start;       // reference batches (gzip member / pandas inference units), + end sentinel
+    // filled by parse
+    std::vector<Span> bc, umi, post, rid;
+    std::vector<double> polyT;               // NaN = blank cell
+    std::vector<uint8_t> ext, ext_len, bc_off, bc_len;
+    // filled by the device
+    std::vector<int32_t> hit;
+    std::vector<int8_t> ed, end_idx;
+    std::vector<uint8_t> flags;
+    // filled by format
+    std::vector<std::string> out;            // per reference batch
+    std::vector<int64_t> demul;
+    int engine = 0, slot = 0;
+};
+
+constexpr int kExtStride = 32;
+
+inline bool is_na_token(const char *s, uint32_t n) {   // pandas' default na_values (parsers STR_NA_VALUES)
+    static const char *const toks[] = {"", "#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN", "-NaN", "-nan", "1.#IND", "1.#QNAN",
+                                       "<NA>", "N/A", "NA", "NULL", "NaN", "None", "n/a", "nan", "null"};
+    for (const char *t : toks)
+        if (strlen(t) == n && memcmp(t, s, n) == 0) return true;
+    return false;
+}
+
+inline bool looks_numeric(const char *s, uint32_t n) {  // would pandas parse this cell as a number?
+    if (n == 0 || n > 63) return false;
+    char tmp[64];
+    memcpy(tmp, s, n); tmp[n] = 0;
+    char *e = nullptr;
+    (void)strtod(tmp, &e);
+    if (e != tmp + n) return false;
+    for (uint32_t i = 0; i < n; ++i) {                  // strtod also takes inf/nan/hex: pandas' tokenizer does not infer those
+        const char c = tmp[i];
+        if (!((c >= '0' && c <= '9') || c == '+' || c == '-' || c == '.' || c == 'e' || c == 'E')) return false;
+    }
+    return true;
+}
+
+// Split one CSV line into up to 7 cells (RFC-4180 quotes as pandas' C parser reads them).  Quoted cells are
+// unescaped into `scratch` (appended to chunk text by the caller's offsets).
+struct Cells { Span c[7]; int n = 0; };
+inline void split_csv(std::vector<char> &text, Span line, Cells &out, std::string &err) {
+    out.n = 0;
+    uint32_t i = line.off;
+    const uint32_t end = line.off + line.len;
+    for (;;) {
+        if (out.n == 7) { err = "putative bc csv: more than 7 cells in a row"; return; }
+        Span cell;
+        if (i < end && text[i] == '"') {               // quoted: unescape in place (result is never longer)
+            uint32_t w = i, r = i + 1;
+            cell.off = w;
+            while (r < end) {
+                if (text[r] == '"') {
+                    if (r + 1 < end && text[r + 1] == '"') { text[w++] = '"'; r += 2; continue; }
+                    ++r; break;
+                }
+                text[w++] = text[r++];
+            }
+            while (r < end && text[r] != ',') text[w++] = text[r++];   // junk after the closing quote is kept, as pandas does
+            cell.len = w - cell.off;
+            i = r;
+        } else {
+            cell.off = i;
+            while (i < end && text[i] != ',') ++i;
+            cell.len = i - cell.off;
+        }
+        out.c[out.n++] = cell;
+        if (i >= end) break;
+        ++i;                                            // the comma
+        if (i == end) { if (out.n < 7) { Span e; e.off = end; e.len = 0; out.c[out.n++] = e; } break; }
+    }
+}
+
+struct Job {
+    std::vector<std::string> fastq_fns;
+    std::string csv, out_path;
+    bool gz = false, restrand = true;
+    int max_ed = 2, batch_size = 1000, n_threads = 8, gz_level = 9;
+    int64_t device_batch_rows = 1 << 16;
+};
+
+struct MismatchError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+template <class F>
+void parallel_for(int n_items, int n_threads, F &&fn) {
+    if (n_items <= 0) return;
+    const int nt = std::max(1, std::min(n_threads, n_items));
+    std::atomic<int> next{0};
+    std::exception_ptr err;
+    std::mutex mu;
+    auto body = [&]() {
+        try {
+            for (int i; (i = next.fetch_add(1)) < n_items;) fn(i);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(mu);
+            if (!err) err = std::current_exception();
+            next.store(n_items);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(body);
+    body();
+    for (auto &t : th) t.join();
+    if (err) std::rethrow_exception(err);
+}
+
+// ---- reader: FASTQ records + the same number of csv lines, cut into device batches of whole reference batches --
+class ChunkReader {
+   public:
+    explicit ChunkReader(const Job &job) : job_(job), csv_(job.csv) {
+        std::vector<char> tmp; Span s;
+        if (!csv_.next(tmp, s)) throw std::runtime_error("putative bc csv is empty: " + job.csv);   // header (:150 `next(f)`)
+    }
+    // Next chunk or nullptr when every FASTQ file is exhausted.
+    std::unique_ptr<Chunk> next() {
+        auto ch = std::make_unique<Chunk>();
+        ch->text.reserve(64 << 20);
+        while ((int64_t)ch->reads.size() < job_.device_batch_rows && ch->text.size() < ((size_t)1 << 30)) {   // spans are 32-bit
+            if (!fq_) {
+                if (file_idx_ >= job_.fastq_fns.size()) break;
+                fq_ = std::make_unique<LineReader>(job_.fastq_fns[file_idx_++]);
+            }
+            // one reference batch: up to batch_size reads of THIS file (helper.batch_iterator is per file, :156-158)
+            const uint32_t start = (uint32_t)ch->reads.size();
+            int got = 0;
+            for (; got < job_.batch_size; ++got) {
+                Read r; Span plus;
+                if (!fq_->next(ch->text, r.id)) break;
+                plus_.clear();
+                if (!fq_->next(ch->text, r.seq) || !fq_->next(plus_, plus) || !fq_->next(ch->text, r.qual))     // '+' line skipped (helper.py:299)
+                    throw std::runtime_error("truncated FASTQ record in " + job_.fastq_fns[file_idx_ - 1]);
+                ch->reads.push_back(r);
+            }
+            if (got == 0) { fq_.reset(); continue; }
+            ch->batch_start.push_back(start);
+            for (int k = 0; k < got; ++k)
+                if (!csv_.next(ch->text, ch->reads[start + k].csv))
+                    throw std::runtime_error("putative bc csv has fewer rows than the FASTQ files have reads");   // StopIteration in the reference
+            if (got < job_.batch_size) fq_.reset();
+            if (ch->text.size() > (size_t)3 << 30) throw std::runtime_error("one batch of reads exceeds 3 GiB of text: lower --batch-size");
+        }
+        if (ch->reads.empty()) return nullptr;
+        ch->batch_start.push_back((uint32_t)ch->reads.size());
+        return ch;
+    }
+
+   private:
+    std::vector<char> plus_;
+    const Job &job_;
+    LineReader csv_;
+    std::unique_ptr<LineReader> fq_;
+    size_t file_idx_ = 0;
+};
+
+inline Span strip(const std::vector<char> &t, Span s) {               // str.strip()
+    while (s.len && py_space((unsigned char)t[s.off])) { ++s.off; --s.len; }
+    while (s.len && py_space((unsigned char)t[s.off + s.len - 1])) --s.len;
+    return s;
+}
+
+// read id: title[1:].split()[0] (helper.py:301) then .split()[0].strip('@') (read_assignment.py:31)
+inline Span fastq_id(const std::vector<char> &t, Span line) {
+    if (line.len) { ++line.off; --line.len; }                         // title[1:]
+    while (line.len && py_space((unsigned char)t[line.off])) { ++line.off; --line.len; }
+    uint32_t n = 0;
+    while (n < line.len && !py_space((unsigned char)t[line.off + n])) ++n;
+    if (n == 0) throw std::runtime_error("FASTQ title line without a read id");   // IndexError in the reference
+    line.len = n;
+    while (line.len && t[line.off] == '@') { ++line.off; --line.len; }
+    while (line.len && t[line.off + line.len - 1] == '@') --line.len;
+    return line;
+}
+
+// ---- parse one reference batch: cells, NA handling, id check, ext rows --------------------------------------
+inline void parse_batch(Chunk &ch, int b) {
+    const uint32_t lo = ch.batch_start[b], hi = ch.batch_start[b + 1];
+    std::string err;
+    bool all_numeric_ids = true;
+    for (uint32_t r = lo; r < hi; ++r) {
+        Read &rd = ch.reads[r];
+        Cells cells;
+        split_csv(ch.text, rd.csv, cells, err);
+        if (!err.empty()) throw std::runtime_error(err);
+        Span cell[7];
+        for (int k = 0; k < 7; ++k) {
+            cell[k] = k < cells.n ? cells.c[k] : Span();
+            if (is_na_token(ch.text.data() + cell[k].off, cell[k].len)) cell[k].len = 0;   // NaN -> fillna('')
+        }
+        // columns: read_id, putative_bc, putative_bc_min_q, putative_umi, polyT_end, pre_bc_flanking, post_umi_flanking
+        ch.rid[r] = cell[0]; ch.bc[r] = cell[1]; ch.umi[r] = cell[3]; ch.post[r] = cell[6];
+        all_numeric_ids = all_numeric_ids && looks_numeric(ch.text.data() + cell[0].off, cell[0].len);
+        double pt = std::numeric_limits<double>::quiet_NaN();
+        if (cell[4].len) {
+            char tmp[64];
+            const uint32_t n = std::min<uint32_t>(cell[4].len, 63);
+            memcpy(tmp, ch.text.data() + cell[4].off, n); tmp[n] = 0;
+            char *e = nullptr;
+            pt = strtod(tmp, &e);
+            if (e != tmp + n || n != cell[4].len) throw std::runtime_error("putative bc csv: polyT_end is not a number: " + std::string(tmp));
+        }
+        ch.polyT[r] = pt;
+        // FASTQ side
+        rd.seq = strip(ch.text, rd.seq);
+        rd.qual = strip(ch.text, rd.qual);
+        rd.id = fastq_id(ch.text, rd.id);
+        if (rd.id.len != cell[0].len || memcmp(ch.text.data() + rd.id.off, ch.text.data() + cell[0].off, rd.id.len) != 0)
+            throw MismatchError("Different order in putative bc file and input fastq!");
+        // ext = pre_bc_flanking[-2:] + putative_bc + putative_umi[:2]   (:70)
+        uint8_t *e = ch.ext.data() + (size_t)r * kExtStride;
+        memset(e, 0, kExtStride);
+        const Span pre = cell[5];
+        if (cell[1].len == 0) { ch.ext_len[r] = ch.bc_off[r] = ch.bc_len[r] = 0; continue; }     // blank row (:61)
+        const uint32_t npre = std::min<uint32_t>(pre.len, 2), numi = std::min<uint32_t>(cell[3].len, 2);
+        const uint32_t total = npre + cell[1].len + numi;
+        if (total > kExtStride) throw std::runtime_error("putative_bc longer than the device row (28 nt)");
+        memcpy(e, ch.text.data() + pre.off + pre.len - npre, npre);
+        memcpy(e + npre, ch.text.data() + cell[1].off, cell[1].len);
+        memcpy(e + npre + cell[1].len, ch.text.data() + cell[3].off, numi);
+        ch.ext_len[r] = (uint8_t)total; ch.bc_off[r] = (uint8_t)npre; ch.bc_len[r] = (uint8_t)cell[1].len;
+    }
+    if (all_numeric_ids && hi > lo)       // pandas would have made read_id a numeric column: `bc.read_id != r.id` (:220)
+        throw MismatchError("Different order in putative bc file and input fastq!");
+}
+
+inline void gzip_member(const std::string &in, std::string &out, int level) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
+    out.resize(deflateBound(&zs, (uLong)in.size()) + 32);
+    zs.next_in = (Bytef *)in.data(); zs.avail_in = (uInt)in.size();
+    zs.next_out = (Bytef *)out.data(); zs.avail_out = (uInt)out.size();
+    const int rc = deflate(&zs, Z_FINISH);
+    const size_t n = zs.total_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END) throw std::runtime_error("deflate failed");
+    out.resize(n);
+}
+
+inline char comp(char c) {                                  // helper.reverse_complement (helper.py:14-25)
+    switch (c) {
+        case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
+        case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a';
+        default: return c;
+    }
+}
+
+// Python slice of a string of length n: [:cut] when neg (cut < 0 given), [cut:] otherwise -> (start, len)
+inline void py_cut(uint32_t n, double polyT, uint32_t &start, uint32_t &len) {
+    const double tr = polyT < 0 ? -std::floor(-polyT) : std::floor(polyT);       // int(): toward zero
+    const int64_t cut = (int64_t)tr;
+    if (polyT < 0) {                                         // seq[:cut], cut <= 0 (cut == 0 only for -1 < x < 0 -> '')
+        const int64_t endp = cut < 0 ? std::max<int64_t>(0, (int64_t)n + cut) : 0;
+        start = 0; len = (uint32_t)endp;
+    } else {                                                 // seq[cut:]
+        const int64_t s = std::min<int64_t>(cut, n);
+        start = (uint32_t)s; len = n - (uint32_t)s;
+    }
+}
+
+// ---- format one reference batch (read_assignment.py:87-99 epilogue + :214-247) ---------------------------------
+inline void format_batch(Chunk &ch, int b, const Job &job, const std::vector<char> &wl_bytes, const std::vector<int64_t> &wl_off) {
+    const uint32_t lo = ch.batch_start[b], hi = ch.batch_start[b + 1];
+    std::string text;
+    int64_t demul = 0;
+    const char *T = ch.text.data();
+    std::string umi;
+    for (uint32_t r = lo; r < hi; ++r) {
+        if (ch.bc[r].len == 0) continue;                     // blank row: BC_corrected == '' (:61-62)
+        const int32_t h = ch.hit[r];
+        if (h < 0) continue;                                 // none / ambiguous (:87-88)
+        const Read &rd = ch.reads[r];
+        const char *bc; uint32_t bcl;
+        umi.assign(T + ch.umi[r].off, ch.umi[r].len);
+        if (ch.flags[r] & 1u) { bc = T + ch.bc[r].off; bcl = ch.bc[r].len; }       // exact shortcut: untouched
+        else {
+            bc = wl_bytes.data() + wl_off[h]; bcl = (uint32_t)(wl_off[h + 1] - wl_off[h]);
+            const int adj = (int)ch.end_idx[r] - ((int)ch.ext_len[r] - 1 - 2);      // :93
+            if (adj > 0) {                                   // umi[adj:] + post[:adj]
+                const uint32_t a = std::min<uint32_t>((uint32_t)adj, (uint32_t)umi.size());
+                umi.erase(0, a);
+                umi.append(T + ch.post[r].off, std::min<uint32_t>((uint32_t)adj, ch.post[r].len));
+            } else if (adj < 0) {                            // putative_bc[adj:] + umi[:adj]
+                const uint32_t k = (uint32_t)(-adj);
+                const Span pb = ch.bc[r];
+                const uint32_t take = std::min(k, pb.len);
+                std::string nu(T + pb.off + pb.len - take, take);
+                if (umi.size() > k) nu.append(umi, 0, umi.size() - k);
+                umi.swap(nu);
+            }
+        }
+        if (bcl == 0) continue;                              // an empty whitelist entry can never be a hit (falsy in :87)
+        ++demul;
+        const double pt = ch.polyT[r];
+        if (pt != pt) throw std::runtime_error("putative bc csv: row with a barcode but no polyT_end");   // TypeError in the reference
+        const char strand = pt == 0 ? 0 : (pt > 0 ? '-' : '+');
+        uint32_t s0, sl, q0, ql;
+        py_cut(rd.seq.len, pt, s0, sl);
+        py_cut(rd.qual.len, pt, q0, ql);
+        text.push_back('@'); text.append(bc, bcl); text.push_back('_'); text.append(umi); text.push_back('#');
+        text.append(T + ch.rid[r].off, ch.rid[r].len); text.push_back('_');
+        if (strand) text.push_back(strand);
+        text.append("\tCB:Z:"); text.append(bc, bcl); text.append("\tUB:Z:"); text.append(umi); text.push_back('\n');
+        const char *sq = T + rd.seq.off + s0, *ql_p = T + rd.qual.off + q0;
+        if (job.restrand && strand == '-') {
+            const size_t at = text.size();
+            text.resize(at + sl);
+            for (uint32_t k = 0; k < sl; ++k) text[at + k] = comp(sq[sl - 1 - k]);
+            text.append("\n+\n");
+            const size_t aq = text.size();
+            text.resize(aq + ql);
+            for (uint32_t k = 0; k < ql; ++k) text[aq + k] = ql_p[ql - 1 - k];
+        } else {
+            text.append(sq, sl); text.append("\n+\n"); text.append(ql_p, ql);
+        }
+        text.push_back('\n');
+    }
+    ch.demul[b] = demul;
+    if (job.gz) gzip_member(text, ch.out[b], job.gz_level);   // one member per batch, also when empty (gzip.compress(b''))
+    else ch.out[b].swap(text);
+}
+
+}  // namespace bzio

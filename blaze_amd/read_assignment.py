@@ -240,17 +240,39 @@ def _device_ids(devices):
     return list(devices)
 
 
+def _assign_files_native(engines, fastq_fns, putative_bc_csv, fastq_out, gz, restrand, max_ed, batchsize,
+                         device_batch_rows, n_threads):
+    """bz_assign_files: the C++ host pipeline (blaze_amd/csrc/host_io.h) around the same device scan."""
+    import ctypes
+    from . import _lib
+    L = _lib.load()
+    handles = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
+    fns = (ctypes.c_char_p * len(fastq_fns))(*[os.fsencode(str(f)) for f in fastq_fns])
+    counts = (ctypes.c_int64 * 4)()
+    rc = L.bz_assign_files(handles, len(engines), fns, len(fastq_fns), os.fsencode(str(putative_bc_csv)),
+                           os.fsencode(str(fastq_out)), int(bool(gz)), int(bool(restrand)), int(max_ed), int(batchsize),
+                           int(device_batch_rows), int(n_threads), counts)
+    if rc == _lib.BZ_E_MISMATCH:                    # the reference's reaction, read_assignment.py:219-223
+        helper.err_msg("Different order in putative bc file and input fastq!", printit=True)
+        sys.exit()
+    _lib.check(rc)
+    return int(counts[0]), int(counts[1])
+
+
 def assign_read(fastq_fns=None, fastq_out=None, putative_bc_csv=None,
                 whitelsit_csv=None, max_ed=None, n_process=None,
                 batchsize=None, minQ=0, restrand=True, args=None, devices=None,
-                device_batch_rows=DEVICE_BATCH_ROWS):
+                device_batch_rows=DEVICE_BATCH_ROWS, host="native"):
     """Demultiplex fastq files using the putative barcode csv and the whitelist csv.
 
     Same arguments as the reference (note its `whitelsit_csv` spelling) or an `args`
     namespace with fastq_fns / output_fastq / out_raw_bc_fn / out_whitelist_fn /
     max_edit_distance / threads / batch_size / restrand.  `n_process` is accepted for
-    compatibility; parallelism comes from the GPUs in `devices` (default: $BLAZE_AMD_DEVICES,
-    else $LOCAL_RANK, else GPU 0).  Returns (reads assigned, reads seen)."""
+    compatibility (it sizes the host thread pool of the native pipeline); device parallelism comes
+    from the GPUs in `devices` (default: $BLAZE_AMD_DEVICES, else $LOCAL_RANK, else GPU 0).
+    host="native" (default) runs the batch loop in C++ (bz_assign_files); host="python" runs the
+    pandas mirror of the reference's loop below.  Both give the same bytes.
+    Returns (reads assigned, reads seen)."""
     if args:
         fastq_fns = args.fastq_fns
         fastq_out = args.output_fastq
@@ -273,6 +295,12 @@ def assign_read(fastq_fns=None, fastq_out=None, putative_bc_csv=None,
     engines = [get_engine(d) for d in _device_ids(devices)]
     for eng in engines:
         _ensure_whitelist(eng, ordered)
+    if host == "native":
+        threads = max(1, min(int(n_process or 1), os.cpu_count() or 1, 64))
+        out = _assign_files_native(engines, fastq_fns, putative_bc_csv, fastq_out, gz, restrand, max_ed, batchsize,
+                                   device_batch_rows, threads)
+        logger.info(helper.green_msg(f"Reads assignment completed. Demultiplexed read saved in {fastq_out}!", printit=False))
+        return out
     n_slots = 2 * len(engines)
     pending = deque()
     demul_count_tot = 0

@@ -42,6 +42,7 @@ typedef struct bz_engine *bz_handle;
 #define BZ_E_STATE (-3)    /* call order (no whitelist, slot empty, comm missing) */
 #define BZ_E_RCCL (-4)     /* RCCL missing or returned an error */
 #define BZ_E_LIMIT (-5)    /* size beyond a documented limit */
+#define BZ_E_MISMATCH (-6) /* putative_bc.csv and the FASTQ files disagree on read order (read_assignment.py:219-223) */
 
 /* options for bz_set_option */
 #define BZ_OPT_TIE_RULE 1      /* 0 = leftmost end index on ties (default), 1 = rightmost.
@@ -113,6 +114,21 @@ int bz_slot_timing(bz_handle h, int slot, float ms[8], int64_t counts[8]);
  * Returns the distance (max_ed+1 above the cut-off, end -1) or a negative error. */
 int bz_sub_edit_distance(bz_handle h, const char *a, int la, const char *b, int lb, int max_ed, int *end_idx);
 int bz_edit_distance(bz_handle h, const char *a, int la, const char *b, int lb, int max_ed);
+
+/* ---- whole step 3 over files ------------------------------------------------------------------------ */
+/* Native host pipeline = assign_read's batch loop (read_assignment.py:253-330) with its generator
+ * (:138-181, helper.py:275-301), per-batch epilogue (:87-99, :214-247) and ordered concatenation
+ * (:293-327): FASTQ(.gz) files + putative_bc.csv in lock step -> device batches on the engines' two
+ * slots each (round robin, drained in submit order) -> trimmed / re-stranded FASTQ records of the
+ * assigned reads, plain or one gzip member per `batch_size` reads per input file (gz != 0).
+ * The whitelist must have been set, in the same order, on every engine.  `batch_size` is the
+ * reference's --batch-size (parser.py:67), `device_batch_rows` the rows per device submit,
+ * `n_threads` the host threads for parsing / formatting / compression.
+ * out_counts: [0] reads assigned (demul_count_tot), [1] reads seen (count_tot), [2] device batches.
+ * Returns BZ_E_MISMATCH (message = the reference's) when a csv row's read_id differs from its read. */
+int bz_assign_files(bz_handle *engines, int n_engines, const char *const *fastq_fns, int n_fastq,
+                    const char *putative_bc_csv, const char *fastq_out, int gz, int restrand, int max_ed,
+                    int batch_size, int64_t device_batch_rows, int n_threads, int64_t out_counts[4]);
 
 /* ---- per-barcode counts + the one collective -------------------------------------------- */
 /* Device-resident int64 histogram counts[0..n_wl) of assigned rows per barcode, followed by

@@ -1,0 +1,207 @@
+"""GPU parity of the native host pipeline (bz_assign_files, blaze_amd/csrc/host_io.h) = SURVEY 8f rows N1 + N2.
+
+Two anchors, both bit-exact on the decompressed FASTQ bytes and the two counts:
+  * the golden end-to-end case recorded from the REAL reference (tests/golden/e2e_leftmost.json);
+  * the pandas host (`assign_read(host="python")`), which mirrors the reference's batch loop line by line and
+    is itself pinned by the goldens, on files that stress what the native parser had to restate: pandas' NA
+    tokens, float-typed polyT_end ("123.0", the form DataFrame.to_csv gives a column with blanks), quoted cells,
+    CRLF line ends, several input files (one gzipped), ragged last batches, title lines with extra tokens.
+"""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from blaze_amd import _lib, synth
+from blaze_amd import read_assignment as ra
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+HEADER = "read_id,putative_bc,putative_bc_min_q,putative_umi,polyT_end,pre_bc_flanking,post_umi_flanking\n"
+
+
+def _load(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+def _text(path):
+    raw = open(path, "rb").read()
+    if str(path).endswith(".gz"):
+        return gzip.decompress(raw)      # multi-member: gzip.decompress concatenates the members
+    return raw
+
+
+def _gz_members(raw):
+    """Number of gzip members in a byte string."""
+    import zlib
+    n = 0
+    while raw:
+        d = zlib.decompressobj(31)
+        d.decompress(raw)
+        raw = d.unused_data
+        n += 1
+    return n
+
+
+@pytest.mark.parametrize("threads", [1, 8])
+@pytest.mark.parametrize("device_batch_rows", [1 << 18, 100])
+def test_native_end_to_end_golden(tmp_path, device_batch_rows, threads):
+    case = _load("e2e_leftmost.json")["case"]
+    pa, pb = tmp_path / "a.fastq", tmp_path / "b.fastq.gz"
+    pa.write_text(case["fastq_a"])
+    with gzip.open(pb, "wt") as f:
+        f.write(case["fastq_b_gz_text"])
+    pc, pw = tmp_path / "putative_bc.csv", tmp_path / "whitelist.csv"
+    pc.write_text(case["csv"])
+    pw.write_text(case["whitelist_text"])
+    for out_name, exp in case["outputs"].items():
+        po = tmp_path / out_name
+        demul, total = ra.assign_read(fastq_fns=[str(pa), str(pb)], fastq_out=str(po), putative_bc_csv=str(pc),
+                                      whitelsit_csv=str(pw), max_ed=case["max_ed"], n_process=threads,
+                                      batchsize=case["batchsize"], restrand=exp["restrand"],
+                                      device_batch_rows=device_batch_rows, host="native")
+        assert _text(po).decode() == exp["fastq"]
+        assert (int(demul), int(total)) == (exp["demul"], exp["total"])
+
+
+def _make_files(tmp_path, n, n_cells, seed, *, crlf=False, float_polyT=True, quirks=True, n_files=3, err=2.0, umi_len=12):
+    """Synthetic step-3 inputs: FASTQ files (second one gzipped), putative_bc.csv, whitelist."""
+    rng = np.random.default_rng(seed)
+    full = synth.full_whitelist_codes(20_000, seed=seed + 1)
+    cells = synth.cell_whitelist_codes(n_cells, full, seed=seed + 2)
+    rows = synth.make_rows(n, cells, full, sub=0.01 * err, ins=0.005 * err, dele=0.005 * err, seed=seed + 3, umi_len=umi_len)
+    ids = synth.read_ids(n, seed=seed + 4)
+    recs = synth.fastq_records(n, ids, seed=seed + 5, median_len=300, min_len=60)
+    s = lambda m, i: m[i].tobytes().decode("ascii")
+    lines = [HEADER]
+    for i in range(n):
+        if rows["blank"][i]:
+            lines.append(f"{ids[i]},,,,,,\n")
+            continue
+        bc, umi, pre, post = s(rows["bc"], i), s(rows["umi"], i), s(rows["pre"], i), s(rows["post"], i)
+        pe = int(rows["polyT_end"][i])
+        if abs(pe) > len(recs[i][1]) and i % 3:
+            pe = int(np.sign(pe)) * int(rng.integers(1, len(recs[i][1])))
+        pe_s = f"{pe}.0" if float_polyT else str(pe)
+        q = int(rows["min_q"][i])
+        if quirks:
+            k = int(rng.integers(0, 40))
+            if k == 0:
+                pre = "NA"                      # a 2-nt flank that pandas reads as NaN -> ''
+            elif k == 1:
+                post = "NA"
+            elif k == 2:
+                pre = ""                        # BC at the very start of the read (polyT_adaptor_finder.py:321)
+            elif k == 3:
+                post = post[:2]
+            elif k == 4:
+                bc = f'"{bc}"'                  # quoted cell
+            elif k == 5:
+                pre = pre[:1]
+            elif k == 6:
+                bc = bc[:7] + "N" + bc[8:]
+            elif k == 7:
+                pe_s = "0"                      # falsy polyT_end: strand '' and nothing trimmed
+            elif k == 8:
+                umi = umi[:1]                   # truncated UMI at the end of a read
+            elif k == 9:
+                pe_s = f"{pe}.7"                # int() truncates toward zero
+            elif k == 10:
+                post = "null"
+        lines.append(f"{ids[i]},{bc},{q},{umi},{pe_s},{pre},{post}\n")
+    nl = "\r\n" if crlf else "\n"
+    csv = "".join(lines).replace("\n", nl)
+    pc = tmp_path / "putative_bc.csv"
+    pc.write_bytes(csv.encode())
+    cuts = sorted(rng.choice(np.arange(1, n), size=n_files - 1, replace=False).tolist()) if n_files > 1 else []
+    bounds = [0] + cuts + [n]
+    fns = []
+    for k in range(n_files):
+        body = "".join(f"@{rid} runid=abc ch={j}\n{seq}\n+{rid if j % 5 == 0 else ''}\n{q}\n"
+                       for j, (rid, seq, q) in enumerate(recs[bounds[k]:bounds[k + 1]])).replace("\n", nl)
+        if k == 1:
+            fn = tmp_path / f"reads_{k}.fastq.gz"
+            with gzip.open(fn, "wb") as f:
+                f.write(body.encode())
+        else:
+            fn = tmp_path / f"reads_{k}.fastq"
+            fn.write_bytes(body.encode())
+        fns.append(str(fn))
+    pw = tmp_path / "whitelist.csv"
+    wl = ["".join(map(chr, w)) for w in synth.codes_to_bytes(cells)]
+    pw.write_text("".join(f"{w}-1\n" for w in wl))
+    return fns, str(pc), str(pw), bounds
+
+
+@pytest.mark.parametrize("crlf,gz,restrand,batchsize,device_batch_rows,threads", [
+    (False, False, True, 1000, 1 << 16, 8),
+    (False, True, True, 333, 700, 3),
+    (True, False, False, 64, 100, 8),
+    (False, True, False, 5000, 1 << 16, 1),
+])
+def test_native_equals_pandas_host(tmp_path, crlf, gz, restrand, batchsize, device_batch_rows, threads):
+    n = 6000
+    fns, pc, pw, bounds = _make_files(tmp_path, n, 500, seed=71 + batchsize, crlf=crlf)
+    suffix = ".fastq.gz" if gz else ".fastq"
+    out_n, out_p = str(tmp_path / ("native" + suffix)), str(tmp_path / ("pandas" + suffix))
+    kw = dict(fastq_fns=fns, putative_bc_csv=pc, whitelsit_csv=pw, max_ed=2, batchsize=batchsize, restrand=restrand,
+              device_batch_rows=device_batch_rows)
+    got_p = ra.assign_read(fastq_out=out_p, n_process=1, host="python", **kw)
+    got_n = ra.assign_read(fastq_out=out_n, n_process=threads, host="native", **kw)
+    assert tuple(map(int, got_n)) == tuple(map(int, got_p))
+    assert got_n[1] == n and 0.3 * n < got_n[0] < n
+    a, b = _text(out_n), _text(out_p)
+    assert a == b
+    if gz:      # member boundaries are the reference's: one per --batch-size reads per input file (:244-245)
+        expect = sum(-(-(hi - lo) // batchsize) for lo, hi in zip(bounds[:-1], bounds[1:]))
+        assert _gz_members(open(out_n, "rb").read()) == expect == _gz_members(open(out_p, "rb").read())
+
+
+def test_native_host_errors(tmp_path):
+    fns, pc, pw, _ = _make_files(tmp_path, 400, 50, seed=5, quirks=False, n_files=1)
+    out = str(tmp_path / "o.fastq")
+    kw = dict(fastq_fns=fns, fastq_out=out, whitelsit_csv=pw, max_ed=2, n_process=4, batchsize=100, host="native")
+    lines = open(pc).read().splitlines(keepends=True)
+    # swapped rows -> the reference's message + sys.exit() (read_assignment.py:219-223)
+    bad = tmp_path / "swapped.csv"
+    bad.write_text("".join([lines[0], lines[2], lines[1]] + lines[3:]))
+    with pytest.raises(SystemExit):
+        ra.assign_read(putative_bc_csv=str(bad), **kw)
+    # fewer csv rows than reads -> StopIteration in the reference, an error here
+    short = tmp_path / "short.csv"
+    short.write_text("".join(lines[:200]))
+    with pytest.raises(_lib.BlazeHipError):
+        ra.assign_read(putative_bc_csv=str(short), **kw)
+    # missing FASTQ
+    with pytest.raises(_lib.BlazeHipError):
+        ra.assign_read(putative_bc_csv=pc, **{**kw, "fastq_fns": [str(tmp_path / "nope.fastq")]})
+    # and the engine still works afterwards
+    assert ra.assign_read(putative_bc_csv=pc, **kw)[1] == 400
+
+
+def test_native_empty_inputs(tmp_path):
+    pw = tmp_path / "wl.csv"
+    pw.write_text("ACGTACGTACGTACGT\nTTTTACGTACGTACGT\n")
+    pc = tmp_path / "p.csv"
+    pc.write_text(HEADER)
+    pf = tmp_path / "empty.fastq"
+    pf.write_text("")
+    for name in ("o.fastq", "o.fastq.gz"):
+        out = tmp_path / name
+        got = ra.assign_read(fastq_fns=[str(pf)], fastq_out=str(out), putative_bc_csv=str(pc), whitelsit_csv=str(pw),
+                             max_ed=2, n_process=2, batchsize=10, host="native")
+        assert tuple(got) == (0, 0) and out.read_bytes() == b""
+
+
+def test_native_configs3_shape_10nt_umi(tmp_path):
+    """BASELINE configs[2]/[4] row shape: 10-nt UMI kits (3v2 / 5v2)."""
+    fns, pc, pw, _ = _make_files(tmp_path, 3000, 800, seed=9, umi_len=10, n_files=2)
+    kw = dict(fastq_fns=fns, putative_bc_csv=pc, whitelsit_csv=pw, max_ed=2, batchsize=500, restrand=True)
+    a = ra.assign_read(fastq_out=str(tmp_path / "n.fastq"), n_process=8, host="native", **kw)
+    b = ra.assign_read(fastq_out=str(tmp_path / "p.fastq"), n_process=1, host="python", **kw)
+    assert tuple(map(int, a)) == tuple(map(int, b))
+    assert (tmp_path / "n.fastq").read_bytes() == (tmp_path / "p.fastq").read_bytes()

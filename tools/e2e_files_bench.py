@@ -1,0 +1,89 @@
+"""End-to-end step 3 over FILES (FASTQ + putative_bc.csv -> demultiplexed FASTQ) on the GPU box's host cores:
+native host pipeline (bz_assign_files) vs the pandas host that mirrors the reference's loop.  Not bench.py's
+metric (that one is HBM-resident); this is the PCIe + file-system + host-CPU inclusive figure of SURVEY 8f N1/N2
+and BASELINE configs[4]'s shape (10-nt UMI, 10k cells, restrand + trim).
+
+usage: python tools/e2e_files_bench.py [n_reads] [n_cells] [threads] [--gz] [--python-too]
+"""
+import gzip
+import json
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from blaze_amd import synth  # noqa: E402
+from blaze_amd import read_assignment as ra  # noqa: E402
+
+
+def write_inputs(d, n, n_cells, umi_len=10, n_files=4, seed=3, median_len=900):
+    full = synth.full_whitelist_codes(400_000, seed=1)
+    cells = synth.cell_whitelist_codes(n_cells, full, seed=2)
+    rows = synth.make_rows(n, cells, full, umi_len=umi_len, seed=seed)
+    ids = synth.read_ids(n, seed=4)
+    rng = np.random.Generator(np.random.PCG64(5))
+    lens = np.maximum(150, rng.lognormal(np.log(median_len), 0.6, size=n).astype(np.int64))
+    pool = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(lens.max()) + (1 << 20))].tobytes()
+    starts = rng.integers(0, 1 << 20, size=n)
+    with open(os.path.join(d, "putative_bc.csv"), "w") as f:
+        f.write(synth.csv_text(rows, ids))
+    fns, per = [], -(-n // n_files)
+    total_bytes = 0
+    for k in range(n_files):
+        fn = os.path.join(d, f"reads_{k}.fastq")
+        with open(fn, "wb") as f:
+            for i in range(k * per, min(n, (k + 1) * per)):
+                L = int(lens[i])
+                s = int(starts[i])
+                rec = b"@" + ids[i].encode() + b" runid=synthetic\n" + pool[s:s + L] + b"\n+\n" + b"I" * L + b"\n"
+                f.write(rec)
+                total_bytes += len(rec)
+        fns.append(fn)
+    wl = os.path.join(d, "whitelist.csv")
+    with open(wl, "w") as f:
+        for w in synth.codes_to_bytes(cells):
+            f.write(w.tobytes().decode() + "-1\n")
+    return fns, os.path.join(d, "putative_bc.csv"), wl, total_bytes
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    n = int(args[0]) if len(args) > 0 else 500_000
+    n_cells = int(args[1]) if len(args) > 1 else 10_000
+    threads = int(args[2]) if len(args) > 2 else 16
+    gz = "--gz" in sys.argv
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
+        t0 = time.time()
+        fns, pc, wl, fq_bytes = write_inputs(d, n, n_cells)
+        gen_s = time.time() - t0
+        out = {"reads": n, "cells": n_cells, "threads": threads, "gz": gz, "fastq_bytes": fq_bytes, "generate_s": gen_s}
+        suffix = ".fastq.gz" if gz else ".fastq"
+        kw = dict(fastq_fns=fns, putative_bc_csv=pc, whitelsit_csv=wl, max_ed=2, batchsize=1000, restrand=True)
+        ra.assign_read(fastq_out=os.path.join(d, "warm" + suffix), n_process=threads, host="native", **kw)   # page cache + engine warm
+        for rep in range(2):
+            t0 = time.time()
+            got = ra.assign_read(fastq_out=os.path.join(d, "native" + suffix), n_process=threads, host="native", **kw)
+            dt = time.time() - t0
+            out[f"native_run{rep}"] = {"s": dt, "reads_per_s": n / dt, "input_GB_per_s": fq_bytes / dt / 1e9,
+                                       "assigned": int(got[0]), "total": int(got[1])}
+        if "--python-too" in sys.argv:
+            m = min(n, 50_000)
+            kw2 = dict(kw)
+            t0 = time.time()
+            sub = os.path.join(d, "sub.fastq")
+            with open(fns[0], "rb") as f, open(sub, "wb") as g:
+                for _ in range(4 * m):
+                    g.write(f.readline())
+            kw2["fastq_fns"] = [sub]
+            t0 = time.time()
+            got = ra.assign_read(fastq_out=os.path.join(d, "pandas" + suffix), n_process=1, host="python", **kw2)
+            dt = time.time() - t0
+            out["pandas_host"] = {"s": dt, "reads": int(got[1]), "reads_per_s": got[1] / dt}
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -105,6 +105,10 @@ struct bz_engine {
     int32_t *d_bucket = nullptr;       // bucket table over the sorted codes' top bits
     int32_t *d_seed_tab[2] = {nullptr, nullptr};      // seed index, plan 0: pieces 5|5|6 (max_ed 2), plan 1: 8|8 (max_ed <= 1)
     int32_t *d_seed_members[2] = {nullptr, nullptr};  // per piece n_wl barcode indices grouped by the piece's code
+    uint32_t *d_pair_bitmap = nullptr;  // pair-seed index (k_scan_paired): 6 x 65536-bit bucket occupancy
+    int32_t *d_pair_tab = nullptr;      //   6 CSR tables over the 16-bit key (piece a code << 8 | piece b code)
+    int32_t *d_pair_members = nullptr;  //   6 x n_wl barcode indices grouped by key, index order inside a bucket
+    int n_cu = 0;
     int bucket_bits = 0, n_blk = 0;
     uint32_t *d_sorted_codes = nullptr;
     int32_t *d_sorted_idx = nullptr;
@@ -139,6 +143,8 @@ void free_whitelist(bz_handle h) {
         hipFree(h->d_seed_tab[k]); hipFree(h->d_seed_members[k]);
         h->d_seed_tab[k] = nullptr; h->d_seed_members[k] = nullptr;
     }
+    hipFree(h->d_pair_bitmap); hipFree(h->d_pair_tab); hipFree(h->d_pair_members);
+    h->d_pair_bitmap = nullptr; h->d_pair_tab = nullptr; h->d_pair_members = nullptr;
     h->d_planes = nullptr; h->d_sorted_codes = nullptr; h->d_sorted_idx = nullptr;
     h->d_wl_bytes = nullptr; h->d_wl_off = nullptr; h->d_counts = nullptr;
     h->n_wl = -1;
@@ -209,6 +215,19 @@ void launch_scan_seeded(bz_handle h, Slot &s) {
                        (int)h->n_wl, s.d_ext, s.stride, s.d_len, s.d_redo, s.d_counters + 2, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
 }
 
+// pair-seeded scan (max_ed 2): persistent workgroups, one per CU; hand-over rows as above
+void launch_scan_paired(bz_handle h, Slot &s) {
+    const int chunks = (int)((s.n + 63) / 64), per_block = bz::kPairThreads / 64;
+    const int grid = std::max(1, std::min(h->n_cu, (chunks + per_block - 1) / per_block));
+    hipLaunchKernelGGL(bz::k_scan_paired<2>, dim3(grid), dim3(bz::kPairThreads), 0, s.stream, h->d_pair_bitmap, h->d_pair_tab,
+                       h->d_pair_members, h->d_planes32, (int)h->n_wl, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters,
+                       h->tie_rule, s.d_redo, s.d_counters + 2, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+    const int block = 256;
+    const int fgrid = (int)((s.n + block - 1) / block);
+    hipLaunchKernelGGL(bz::k_scan_filtered<2>, dim3(fgrid), dim3(block), 0, s.stream, (const uint4 *)h->d_grams, h->d_planes32, h->n_blk,
+                       (int)h->n_wl, s.d_ext, s.stride, s.d_len, s.d_redo, s.d_counters + 2, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+}
+
 // the striped totals behind counts[n_wl+2] -> counts[n_wl], counts[n_wl+1]
 int fold_totals(bz_handle h, hipStream_t st) {
     hipLaunchKernelGGL(bz::k_fold_totals, dim3(1), dim3(64), 0, st, h->d_counts, (int)h->n_wl);
@@ -250,6 +269,11 @@ int bz_create(int device, bz_handle *out) {
     HIP_TRY(hipSetDevice(device));
     bz_engine *h = new bz_engine();
     h->device = device;
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        h->n_cu = std::max(1, prop.multiProcessorCount);
+    }
     for (Slot &s : h->slot) {
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         for (hipEvent_t &e : s.ev) HIP_TRY(hipEventCreate(&e));
@@ -286,7 +310,7 @@ int bz_set_option(bz_handle h, int option, int64_t value) {
         case BZ_OPT_TIE_RULE: if (value != 0 && value != 1) return fail(BZ_E_ARG, "tie rule must be 0 or 1"); h->tie_rule = (int)value; return BZ_OK;
         case BZ_OPT_SHORTCUT: h->shortcut = value ? 1 : 0; return BZ_OK;
         case BZ_OPT_FORCE_GENERIC: h->force_generic = value ? 1 : 0; return BZ_OK;
-        case BZ_OPT_SCAN_MODE: if (value < 0 || value > 2) return fail(BZ_E_ARG, "scan mode must be 0, 1 or 2"); h->scan_mode = (int)value; return BZ_OK;
+        case BZ_OPT_SCAN_MODE: if (value < 0 || value > 3) return fail(BZ_E_ARG, "scan mode must be 0..3"); h->scan_mode = (int)value; return BZ_OK;
     }
     return fail(BZ_E_ARG, "unknown option %d", option);
 }
@@ -417,6 +441,34 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
             HIP_TRY(hipMemcpy(h->d_seed_tab[pl], tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(h->d_seed_members[pl], mem.data(), mem.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         }
+
+        // pair-seed index (k_scan_paired, max_ed 2): the barcode is cut into four 4-nt pieces; per pair of pieces a
+        // CSR table over the 16-bit key + an occupancy bitmap the kernel keeps in LDS
+        {
+            const int pa[bz::kPairCount] = {0, 0, 0, 1, 1, 2}, pb[bz::kPairCount] = {1, 2, 3, 2, 3, 3};
+            std::vector<uint32_t> bitmap((size_t)bz::kPairCount * bz::kPairBmWords, 0u);
+            std::vector<int32_t> tab((size_t)bz::kPairCount * bz::kPairTab), mem((size_t)bz::kPairCount * n);
+            for (int p = 0; p < bz::kPairCount; ++p) {
+                auto key = [&](int64_t k) { return (((codes[k] >> (8 * pa[p])) & 0xFFu) << 8) | ((codes[k] >> (8 * pb[p])) & 0xFFu); };
+                int32_t *t = tab.data() + (size_t)p * bz::kPairTab;
+                std::fill(t, t + bz::kPairTab, 0);
+                for (int64_t k = 0; k < n; ++k) {
+                    const uint32_t ky = key(k);
+                    ++t[ky + 1];
+                    bitmap[(size_t)p * bz::kPairBmWords + (ky >> 5)] |= 1u << (ky & 31u);
+                }
+                for (int b = 0; b < bz::kPairTab - 1; ++b) t[b + 1] += t[b];
+                std::vector<int32_t> fill(t, t + bz::kPairTab - 1);
+                int32_t *m = mem.data() + (size_t)p * n;
+                for (int64_t k = 0; k < n; ++k) m[fill[key(k)]++] = (int32_t)k;
+            }
+            HIP_TRY(hipMalloc(&h->d_pair_bitmap, bitmap.size() * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc(&h->d_pair_tab, tab.size() * sizeof(int32_t)));
+            HIP_TRY(hipMalloc(&h->d_pair_members, mem.size() * sizeof(int32_t)));
+            HIP_TRY(hipMemcpy(h->d_pair_bitmap, bitmap.data(), bitmap.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(h->d_pair_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(h->d_pair_members, mem.data(), mem.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
     }
     h->n_wl = n;
     return BZ_OK;
@@ -473,12 +525,13 @@ int bz_assign_run(bz_handle h, int slot, int max_ed) {
         // filter + verify over the whole whitelist; mode 1 = brute force (also what max_ed 3 takes: its
         // seeds and 3-gram sets are too weak to pay)
         // (event words hold the barcode index in 25 bits: larger whitelists take the filtered scan)
-        const bool seeded = h->scan_mode == 0 && max_ed <= 2 && h->n_wl < ((int64_t)1 << 25);
+        const bool seeded = (h->scan_mode == 0 || h->scan_mode == 3) && max_ed <= 2 && h->n_wl < ((int64_t)1 << 25);
         const bool filtered = !seeded && h->scan_mode != 1 && max_ed <= 2;
         switch (max_ed) {
             case 0: if (seeded) launch_scan_seeded<0>(h, s); else if (filtered) launch_scan_filtered<0>(h, s); else launch_scan<0>(h, s); break;
             case 1: if (seeded) launch_scan_seeded<1>(h, s); else if (filtered) launch_scan_filtered<1>(h, s); else launch_scan<1>(h, s); break;
-            case 2: if (seeded) launch_scan_seeded<2>(h, s); else if (filtered) launch_scan_filtered<2>(h, s); else launch_scan<2>(h, s); break;
+            case 2: if (seeded && h->scan_mode == 0 && (s.stride & 15) == 0 && s.stride >= 32) launch_scan_paired(h, s); else if (seeded) launch_scan_seeded<2>(h, s);
+                    else if (filtered) launch_scan_filtered<2>(h, s); else launch_scan<2>(h, s); break;
             default: launch_scan<3>(h, s); break;
         }
         HIP_TRY(hipGetLastError());

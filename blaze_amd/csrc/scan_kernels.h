@@ -27,6 +27,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace bz {
 
 constexpr int kBcLen = 16;        // config.py:34
@@ -47,6 +49,13 @@ struct RowBytes {
     uint32_t w[8];
     __device__ __forceinline__ uint32_t at(int j) const { return (w[j >> 2] >> (8 * (j & 3))) & 0xFFu; }
 };
+__device__ __forceinline__ RowBytes load_row_packed(const uint8_t *row) {      // packed layout only (host checks the stride)
+    RowBytes b;
+    const uint4 lo = *(const uint4 *)row, hi = *(const uint4 *)(row + 16);
+    b.w[0] = lo.x; b.w[1] = lo.y; b.w[2] = lo.z; b.w[3] = lo.w;
+    b.w[4] = hi.x; b.w[5] = hi.y; b.w[6] = hi.z; b.w[7] = hi.w;
+    return b;
+}
 __device__ __forceinline__ RowBytes load_row(const uint8_t *row, int stride) {
     RowBytes b;
     if ((stride & 15) == 0 && stride >= 32) {                 // wave-uniform
@@ -584,6 +593,227 @@ __global__ __launch_bounds__(256) void k_scan_seeded(
     ed_out[r] = (int8_t)best;
     end_out[r] = (int8_t)(hit >= 0 ? hit_end : -1);
     flags_out[r] = (uint8_t)(hit == kHitAmbiguous ? kFlagAmbig : 0u);
+}
+
+// ------------------------------------------------------------------------------------------
+// Pair-seeded scan (the product path for max_ed == 2): "2 untouched pieces of 4" + packed verify.
+//
+// Lemma: cut the 16-nt barcode P into FOUR 4-nt pieces.  An edit operation touches at most one piece
+// (an insertion between two pieces touches none), so an alignment of P inside the text T with <= 2
+// operations leaves at least TWO pieces a < b untouched, both verbatim in T: piece a at column
+// ja = s + 4a + d_a and piece b at jb = ja + 4(b-a) + delta, where s >= 0 is the start of the matched
+// substring, d_a the net indel shift in front of piece a (|d_a| <= 2) and delta the net shift between
+// the two pieces (|delta| <= 2; between ADJACENT pieces only insertions fit, delta >= 0).  The end of the
+// alignment must fit a text of <= 20 columns, which bounds ja - 4a to [-2, 6] (same derivation as the
+// single-piece windows above).  So the barcodes whose pieces (a, b) equal the text windows (ja, jb) for
+// one of the 6 pairs x 9 x 5 (minus the statically impossible ones: 162 probes) are a SUPERSET of
+// {w : sub_ed(w, T) <= 2}; a barcode outside it can never enter the reference's fold (:73-85).
+//
+// The key of a probe is 16 bits (two 4-nt codes), so per pair a 65536-bit occupancy bitmap (8 KB; all
+// six = 48 KB) lives in LDS and ~92 % of the probes of a 5k-cell list end there; the rest look up a CSR
+// table (tab2 / members2) in L2.  A read meets ~18 candidates (5k cells) instead of ~88 with the three
+// single-piece seeds, and ~1/330 of a 6.8M list instead of 1/38.
+//
+// Persistent workgroups of 1024 lanes (one per CU, 144 KB LDS: bitmaps + per-lane FIFO + events): each
+// wave takes 64-row chunks of the work list with a grid stride, so the bitmaps are loaded once per CU
+// and there is no tail of half-empty workgroups.  Verify, events and the replay of the ordered fold are
+// the ones of k_scan_seeded.
+constexpr int kPairCount = 6;
+constexpr int kPairBmWords = 2048;                                // 65536 bits per pair
+constexpr int kPairTab = 65537;
+constexpr int kPairQCap = 16;                                     // FIFO entries per lane
+constexpr int kPairPop = 4;                                       // probes decoded per lane per step
+constexpr int kPairThreads = 1024;
+
+template <int K>
+__global__ __launch_bounds__(kPairThreads) void k_scan_paired(
+    const uint32_t *__restrict__ bitmap, const int32_t *__restrict__ tab2, const int32_t *__restrict__ members2,
+    const uint32_t *__restrict__ planes32, int n_wl,
+    const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
+    const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int tie,
+    int32_t *__restrict__ redo_list, int32_t *__restrict__ n_redo,
+    int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
+    static_assert(K == 2, "the pair lemma is stated for two edit operations");
+    __shared__ uint32_t bm[kPairCount * kPairBmWords];
+    __shared__ uint32_t fifo[kPairQCap][kPairThreads];
+    __shared__ uint32_t events[kMaxEvents][kPairThreads];
+    const int n_list = *n_list_ptr;
+    const int n_chunks = (n_list + 63) >> 6;
+    const int tid = threadIdx.x;
+    const int waves_per_block = kPairThreads / 64;
+    if ((int)blockIdx.x * waves_per_block >= n_chunks) return;    // workgroup-uniform: nothing to do here
+    for (int i = tid; i < kPairCount * kPairBmWords; i += kPairThreads) bm[i] = bitmap[i];
+    __syncthreads();
+    const uint32_t one = in_vgpr(kOne2);
+    constexpr int kFirst = kBcLen - K - 1;
+
+    for (int chunk = blockIdx.x * waves_per_block + (tid >> 6); chunk < n_chunks; chunk += gridDim.x * waves_per_block) {
+        const int slot = chunk * 64 + (tid & 63);
+        const bool active = slot < n_list;
+        const int r = list[active ? slot : n_list - 1];
+        const int len = ext_len[r];
+
+        uint32_t XH[kTextCols], XL[kTextCols];
+        uint64_t tc = 0;                                          // 2-bit codes of the text, column j at bits 2j
+        {
+            const RowBytes rb = load_row_packed(ext + (size_t)r * ext_stride);
+#pragma unroll
+            for (int j = 0; j < kTextCols; ++j) {
+                const uint32_t c = (j < len) ? rb.at(j) : (uint32_t)'A';   // padding can only add candidates
+                const uint32_t code = base_code(c);
+                XH[j] = (code & 2u) ? 0u : 0xFFFFFFFFu;
+                XL[j] = (code & 1u) ? 0u : 0xFFFFFFFFu;
+                tc |= (uint64_t)code << (2 * j);
+            }
+        }
+        uint32_t head = 0, tail = 0;
+        int nev = 0;
+        bool overflow = false;
+
+        auto verify_round = [&]() {                               // as in k_scan_seeded
+            const uint32_t cnt = tail - head;
+            const bool have = cnt != 0;
+            uint32_t i0 = fifo[head & (kPairQCap - 1)][tid], i1 = fifo[(head + 1) & (kPairQCap - 1)][tid];   // unconditional reads
+            i0 = have ? i0 : 0u;
+            i1 = cnt > 1 ? i1 : i0;
+            head += cnt > 1 ? 2u : (have ? 1u : 0u);
+            const uint32_t p0 = planes32[i0], p1 = planes32[i1];
+            const uint32_t bh = (p0 & 0xFFFFu) | (p1 << 16), bl = (p0 >> 16) | (p1 & 0xFFFF0000u);
+            PackedScan<K> A;
+            A.init();
+            uint32_t H = 0, P = 0;
+#pragma unroll
+            for (int j = 0; j < kTextCols; ++j) {
+                const uint32_t eq = BZ_LUT3(bh ^ XH[j], bl, XL[j], kTA & (kTB ^ kTC));
+                if (j == kTextCols - 1) A.template step<true>(eq, one);
+                else A.template step<false>(eq, one);
+                if (j >= kFirst) {
+                    if (((j - kFirst) & 1) == 0) P = A.R[K];
+                    else H = BZ_LUT3(H, P, A.R[K], kTA | kTB | kTC);
+                }
+            }
+            if (((kTextCols - 1 - kFirst) & 1) == 0) H |= P;
+            uint32_t cand = ((H >> 15) & 1u) | ((H >> 30) & 2u);
+            if (!have || !active) cand = 0;
+            if (cnt < 2) cand &= 1u;
+            while (cand) {                                        // rare, divergent, exact
+                const int k = __ffs(cand) - 1;
+                cand &= cand - 1;
+                const uint32_t p = k ? p1 : p0;
+                int ed, end;
+                exact_pair<K>(p & 0xFFFFu, p >> 16, XH, XL, len, tie, ed, end);
+                if (ed <= K) {                                    // a barcode met through several probes is recorded once
+                    const uint32_t ev = ((k ? i1 : i0) << 7) | ((uint32_t)ed << 5) | (uint32_t)end;
+                    bool seen = false;
+                    for (int a = 0; a < nev; ++a) seen = seen || events[a][tid] == ev;
+                    if (!seen) {
+                        if (nev < kMaxEvents) events[nev++][tid] = ev;
+                        else overflow = true;
+                    }
+                }
+            }
+        };
+
+        const uint32_t tlo_ = (uint32_t)tc, thi_ = (uint32_t)(tc >> 32);
+        // one pair of pieces (PA, PB static): probe the pair's bitmap for every admissible window pair, then turn
+        // the occupied buckets into FIFO candidates
+        auto do_pair = [&](auto pa_c, auto pb_c, auto p_c) {
+            constexpr int a = decltype(pa_c)::value, b = decltype(pb_c)::value, p = decltype(p_c)::value;
+            uint32_t mlo = 0, mhi = 0;                            // bit (5 xi + di) <=> windows (ja, jb) name an occupied bucket
+            // (opaque copies: otherwise the window codes of all six pairs are computed up front and spilled)
+            const uint32_t tlo = in_vgpr(tlo_), thi = in_vgpr(thi_);
+#pragma unroll
+            for (int xi = 0; xi < 9; ++xi) {
+#pragma unroll
+                for (int di = 0; di < 5; ++di) {
+                    const int ja = 4 * a - 2 + xi, jb = ja + 4 * (b - a) + di - 2;
+                    const bool ok = ja >= 0 && ja + 4 <= kTextCols && jb >= 0 && jb + 4 <= kTextCols &&
+                                    !(b == a + 1 && di < 2);      // adjacent pieces: only insertions fit between them
+                    if (ok) {
+                        const uint32_t ca = 2 * ja + 8 <= 32 ? (tlo >> (2 * ja)) : 2 * ja >= 32 ? (thi >> ((2 * ja) & 31)) : __builtin_amdgcn_alignbit(thi, tlo, (2 * ja) & 31);
+                        const uint32_t cb = 2 * jb + 8 <= 32 ? (tlo >> (2 * jb)) : 2 * jb >= 32 ? (thi >> ((2 * jb) & 31)) : __builtin_amdgcn_alignbit(thi, tlo, (2 * jb) & 31);
+                        const uint32_t key = ((ca & 0xFFu) << 8) | (cb & 0xFFu);
+                        const uint32_t w = bm[p * kPairBmWords + (key >> 5)];
+                        const uint32_t bit = (w >> (key & 31u)) & 1u;
+                        const int pos = 5 * xi + di;
+                        if (pos < 32) mlo |= bit << (pos & 31); else mhi |= bit << ((pos - 32) & 31);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);                // at most five bitmap reads in flight: keeps the live set small
+            }
+            if (!active) { mlo = 0; mhi = 0; }
+            const int32_t *tp = tab2 + (size_t)p * kPairTab;
+            const int32_t *mp = members2 + (size_t)p * n_wl;
+            const uint64_t tcc = ((uint64_t)thi << 32) | tlo;
+            while (__builtin_amdgcn_ballot_w64((mlo | mhi) != 0) != 0) {
+                // straight-line on purpose (no divergent branches): every lane pops up to kPairPop hits and all the
+                // table look-ups of the step are in flight together; idle lanes read bucket 0 and drop it
+                int cur[kPairPop], end[kPairPop];
+                uint2 se[kPairPop];
+#pragma unroll
+                for (int q = 0; q < kPairPop; ++q) {
+                    const bool lo = mlo != 0;
+                    const uint32_t w = lo ? mlo : mhi;
+                    const bool h = w != 0;
+                    const int pos = (int)__builtin_ctz(w | 0x80000000u) + (lo ? 0 : 32);
+                    const uint32_t w2 = w & (w - 1u);
+                    mlo = lo ? w2 : mlo;
+                    mhi = lo ? mhi : w2;
+                    const int xi = (pos * 13) >> 6, di = pos - 5 * xi;          // pos / 5, pos % 5 for pos < 64
+                    const int ja = 4 * a - 2 + xi, jb = ja + 4 * (b - a) + di - 2;
+                    const uint32_t key = (((uint32_t)(tcc >> ((2 * ja) & 63)) & 0xFFu) << 8) | ((uint32_t)(tcc >> ((2 * jb) & 63)) & 0xFFu);
+                    const int32_t *e = tp + (h ? key : 0u);
+                    se[q] = make_uint2((uint32_t)e[0], (uint32_t)e[1]);
+                    cur[q] = h ? (int)se[q].x : 0; end[q] = h ? (int)se[q].y : 0;
+                }
+                for (;;) {
+                    bool any = false;
+#pragma unroll
+                    for (int q = 0; q < kPairPop; ++q) any = any || cur[q] < end[q];
+                    if (__builtin_amdgcn_ballot_w64(any) == 0) break;
+                    while (__builtin_amdgcn_ballot_w64((tail - head) > (uint32_t)(kPairQCap - kPairPop)) != 0) verify_round();
+                    int32_t mm[kPairPop];
+#pragma unroll
+                    for (int q = 0; q < kPairPop; ++q) mm[q] = mp[cur[q] < end[q] ? cur[q] : 0];
+#pragma unroll
+                    for (int q = 0; q < kPairPop; ++q) {                        // the slot at `tail` is free: unconditional store
+                        fifo[tail & (kPairQCap - 1)][tid] = (uint32_t)mm[q];
+                        tail += cur[q] < end[q] ? 1u : 0u;
+                        ++cur[q];
+                    }
+                }
+            }
+        };
+#define BZ_PAIR(A, B, P) do_pair(std::integral_constant<int, A>{}, std::integral_constant<int, B>{}, std::integral_constant<int, P>{})
+        BZ_PAIR(0, 1, 0); BZ_PAIR(0, 2, 1); BZ_PAIR(0, 3, 2); BZ_PAIR(1, 2, 3); BZ_PAIR(1, 3, 4); BZ_PAIR(2, 3, 5);
+#undef BZ_PAIR
+        while (__builtin_amdgcn_ballot_w64(tail != head) != 0) verify_round();
+
+        if (!active) continue;
+        if (overflow) {                                           // too many near matches: finish in whitelist order
+            redo_list[atomicAdd(n_redo, 1)] = r;
+            continue;
+        }
+        for (int a = 1; a < nev; ++a) {                           // events in whitelist order (insertion sort)
+            const uint32_t v = events[a][tid];
+            int b = a - 1;
+            while (b >= 0 && events[b][tid] > v) { events[b + 1][tid] = events[b][tid]; --b; }
+            events[b + 1][tid] = v;
+        }
+        int best = K, hit = kHitNone, hit_end = -1;
+        bool done = false;
+        uint32_t prev = 0xFFFFFFFFu;
+        for (int a = 0; a < nev; ++a) {
+            const uint32_t v = events[a][tid];
+            if (v == prev) continue;
+            prev = v;
+            fold_update((int)((v >> 5) & 3u), (int)(v & 31u), (int)(v >> 7), best, hit, hit_end, done);
+        }
+        hit_out[r] = hit >= 0 ? hit : -1;
+        ed_out[r] = (int8_t)best;
+        end_out[r] = (int8_t)(hit >= 0 ? hit_end : -1);
+        flags_out[r] = (uint8_t)(hit == kHitAmbiguous ? kFlagAmbig : 0u);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -58,6 +58,18 @@
 #define I_LSHLADD(k) "v_lshl_add_u32 %" #k ", %" #k ", 1, %8\n"
 #define I_FILTER(k) "v_and_b32 %" #k ", %8, %" #k "\n" "v_bcnt_u32_b32 %" #k ", %" #k ", %9\n" "v_alignbit_b32 %" #k ", %8, %" #k ", 31\n"
 
+#define I_BFEI(k) "v_bfe_i32 %" #k ", %" #k ", 5, 1\n"
+#define I_BFEU(k) "v_bfe_u32 %" #k ", %" #k ", 6, 8\n"
+#define I_BFEU_V(k) "v_bfe_u32 %" #k ", %8, %" #k ", 1\n"
+#define I_ASHR(k) "v_ashrrev_i32 %" #k ", 31, %" #k "\n"
+#define I_LSHRV(k) "v_lshrrev_b32 %" #k ", %8, %" #k "\n"
+#define I_MAD24(k) "v_mad_u32_u24 %" #k ", %" #k ", %8, %9\n"
+KERNEL(k_bfe_i32, REP8(I_BFEI))
+KERNEL(k_bfe_u32, REP8(I_BFEU))
+KERNEL(k_bfe_u32_v, REP8(I_BFEU_V))
+KERNEL(k_ashr, REP8(I_ASHR))
+KERNEL(k_lshr_v, REP8(I_LSHRV))
+KERNEL(k_mad24, REP8(I_MAD24))
 KERNEL(k_xor, REP8(I_XOR))
 KERNEL(k_xor_s, REP8(I_XOR_S))
 KERNEL(k_and, REP8(I_AND))
@@ -113,7 +125,9 @@ int main() {
         {"v_cmp_le_u32 + v_addc_co_u32", k_cmp_addc, 16}, {"v_cmp_le_u32 vcc", k_cmp, 8}, {"v_cndmask_b32 vcc", k_cndmask, 8},
         {"v_lshrrev_b32", k_lshr, 8}, {"v_sub_u32", k_sub, 8}, {"v_or_b32", k_or, 8}, {"v_min_u32", k_min, 8},
         {"v_perm_b32", k_perm, 8}, {"v_bitop3 andn 2src", k_andn, 8}, {"v_add3_u32", k_add3, 8}, {"v_lshl_add_u32", k_lshladd, 8},
-        {"filter mix and+bcnt+alignbit", k_filter, 24}};
+        {"filter mix and+bcnt+alignbit", k_filter, 24},
+        {"v_bfe_i32 imm", k_bfe_i32, 8}, {"v_bfe_u32 imm", k_bfe_u32, 8}, {"v_bfe_u32 vgpr offset", k_bfe_u32_v, 8},
+        {"v_ashrrev_i32 imm", k_ashr, 8}, {"v_lshrrev_b32 vgpr shift", k_lshr_v, 8}, {"v_mad_u32_u24", k_mad24, 8}};
     const int threads = 256, iters = 4000;
     uint32_t *d;
     hipMalloc(&d, (size_t)p.multiProcessorCount * 8 * threads * 4);

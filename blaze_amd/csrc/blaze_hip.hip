@@ -85,6 +85,9 @@ struct Slot {
     uint8_t *d_ext = nullptr, *d_len = nullptr, *d_off = nullptr, *d_bcl = nullptr, *d_flags = nullptr;
     int32_t *d_hit = nullptr, *d_fast = nullptr, *d_gen = nullptr, *d_redo = nullptr, *d_counters = nullptr;
     int8_t *d_ed = nullptr, *d_end = nullptr;
+    uint32_t *d_cand = nullptr, *d_cand_cnt = nullptr;   // candidate lists of the pair-seeded scan: cand[s][slot], cap x cand_stride
+    int64_t cand_words = 0;
+    int cand_stride = 0;
     // pinned host staging
     uint8_t *h_in = nullptr, *h_out = nullptr;
     int32_t *h_counters = nullptr;
@@ -94,7 +97,7 @@ struct Slot {
 
 struct bz_engine {
     int device = 0;
-    int tie_rule = 0, shortcut = 1, force_generic = 0, scan_mode = 0;
+    int tie_rule = 0, shortcut = 1, force_generic = 0, scan_mode = 0, pair_fused = 0;
     // whitelist
     int64_t n_wl = -1;
     int wl_regular = 0;
@@ -108,6 +111,8 @@ struct bz_engine {
     uint32_t *d_pair_bitmap = nullptr;  // pair-seed index (k_scan_paired): 6 x 65536-bit bucket occupancy
     int32_t *d_pair_tab = nullptr;      //   6 CSR tables over the 16-bit key (piece a code << 8 | piece b code)
     int32_t *d_pair_members = nullptr;  //   6 x n_wl barcode indices grouped by key, index order inside a bucket
+    uint2 *d_pair_tab8 = nullptr;       //   6 x 65536 {bucket size, the barcode (size 1) or offset into members} (k_pair_candidates)
+    int pair_cap = 0;                   //   candidate slots per row for the two-kernel form, 0 = use k_scan_paired
     int n_cu = 0;
     int bucket_bits = 0, n_blk = 0;
     uint32_t *d_sorted_codes = nullptr;
@@ -143,8 +148,9 @@ void free_whitelist(bz_handle h) {
         hipFree(h->d_seed_tab[k]); hipFree(h->d_seed_members[k]);
         h->d_seed_tab[k] = nullptr; h->d_seed_members[k] = nullptr;
     }
-    hipFree(h->d_pair_bitmap); hipFree(h->d_pair_tab); hipFree(h->d_pair_members);
-    h->d_pair_bitmap = nullptr; h->d_pair_tab = nullptr; h->d_pair_members = nullptr;
+    hipFree(h->d_pair_bitmap); hipFree(h->d_pair_tab); hipFree(h->d_pair_members); hipFree(h->d_pair_tab8);
+    h->d_pair_bitmap = nullptr; h->d_pair_tab = nullptr; h->d_pair_members = nullptr; h->d_pair_tab8 = nullptr;
+    h->pair_cap = 0;
     h->d_planes = nullptr; h->d_sorted_codes = nullptr; h->d_sorted_idx = nullptr;
     h->d_wl_bytes = nullptr; h->d_wl_off = nullptr; h->d_counts = nullptr;
     h->n_wl = -1;
@@ -154,6 +160,8 @@ void free_slot(Slot &s) {
     hipFree(s.d_ext); hipFree(s.d_len); hipFree(s.d_off); hipFree(s.d_bcl); hipFree(s.d_flags);
     hipFree(s.d_hit); hipFree(s.d_fast); hipFree(s.d_gen); hipFree(s.d_redo); hipFree(s.d_ed); hipFree(s.d_end);
     hipHostFree(s.h_in); hipHostFree(s.h_out);
+    hipFree(s.d_cand); hipFree(s.d_cand_cnt);
+    s.d_cand = s.d_cand_cnt = nullptr; s.cand_words = 0; s.cand_stride = 0;
     s.d_ext = s.d_len = s.d_off = s.d_bcl = s.d_flags = nullptr;
     s.d_hit = s.d_fast = s.d_gen = s.d_redo = nullptr;
     s.d_ed = s.d_end = nullptr;
@@ -213,6 +221,34 @@ void launch_scan_seeded(bz_handle h, Slot &s) {
                        s.d_counters + 2, s.d_hit, s.d_ed, s.d_end, s.d_flags);
     hipLaunchKernelGGL(bz::k_scan_filtered<K>, dim3(grid), dim3(block), 0, s.stream, (const uint4 *)h->d_grams, h->d_planes32, h->n_blk,
                        (int)h->n_wl, s.d_ext, s.stride, s.d_len, s.d_redo, s.d_counters + 2, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+}
+
+// pair-seeded scan, two-kernel form (whitelists whose candidate lists fit `pair_cap` slots per row)
+int launch_pair_two_kernels(bz_handle h, Slot &s) {
+    const int stride = (int)((s.n + 63) / 64 * 64);
+    const int64_t need = (int64_t)h->pair_cap * stride;
+    if (need > s.cand_words || !s.d_cand_cnt) {
+        HIP_TRY(hipStreamSynchronize(s.stream));
+        hipFree(s.d_cand); hipFree(s.d_cand_cnt);
+        s.d_cand = s.d_cand_cnt = nullptr; s.cand_words = 0;
+        const int64_t rows = std::max<int64_t>(s.cap, stride);
+        HIP_TRY(hipMalloc(&s.d_cand, (size_t)h->pair_cap * rows * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&s.d_cand_cnt, (size_t)rows * sizeof(uint32_t)));
+        s.cand_words = (int64_t)h->pair_cap * rows;
+    }
+    s.cand_stride = stride;
+    const int ga = (int)((s.n + bz::kCandThreads - 1) / bz::kCandThreads);
+    hipLaunchKernelGGL(bz::k_pair_candidates, dim3(ga), dim3(bz::kCandThreads), 0, s.stream, h->d_pair_bitmap, h->d_pair_tab8,
+                       h->d_pair_members, (int)h->n_wl, s.d_ext, s.stride, s.d_fast, s.d_counters, s.d_cand, stride, h->pair_cap,
+                       s.d_cand_cnt);
+    const int block = 256;
+    const int grid = (int)((s.n + block - 1) / block);
+    hipLaunchKernelGGL(bz::k_pair_verify<2>, dim3(grid), dim3(block), 0, s.stream, s.d_cand, stride, s.d_cand_cnt, h->d_planes32,
+                       s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_redo, s.d_counters + 2, s.d_hit, s.d_ed,
+                       s.d_end, s.d_flags);
+    hipLaunchKernelGGL(bz::k_scan_filtered<2>, dim3(grid), dim3(block), 0, s.stream, (const uint4 *)h->d_grams, h->d_planes32, h->n_blk,
+                       (int)h->n_wl, s.d_ext, s.stride, s.d_len, s.d_redo, s.d_counters + 2, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+    return BZ_OK;
 }
 
 // pair-seeded scan (max_ed 2): persistent workgroups, one per CU; hand-over rows as above
@@ -311,6 +347,7 @@ int bz_set_option(bz_handle h, int option, int64_t value) {
         case BZ_OPT_SHORTCUT: h->shortcut = value ? 1 : 0; return BZ_OK;
         case BZ_OPT_FORCE_GENERIC: h->force_generic = value ? 1 : 0; return BZ_OK;
         case BZ_OPT_SCAN_MODE: if (value < 0 || value > 3) return fail(BZ_E_ARG, "scan mode must be 0..3"); h->scan_mode = (int)value; return BZ_OK;
+        case BZ_OPT_PAIR_FUSED: h->pair_fused = value ? 1 : 0; return BZ_OK;
     }
     return fail(BZ_E_ARG, "unknown option %d", option);
 }
@@ -468,6 +505,24 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
             HIP_TRY(hipMemcpy(h->d_pair_bitmap, bitmap.data(), bitmap.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(h->d_pair_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(h->d_pair_members, mem.data(), mem.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            // two-kernel form: 8-byte table entries and a per-row candidate capacity of twice the expected number of
+            // chance candidates (162 probes x bucket occupancy) plus room for the true ones
+            const double chance = 162.0 * (double)n / 65536.0;
+            const int cap = (int)((2.0 * chance + 40.0) / 8.0) * 8;
+            if (cap <= 256) {
+                std::vector<uint2> tab8((size_t)bz::kPairCount * 65536);
+                for (int p = 0; p < bz::kPairCount; ++p) {
+                    const int32_t *t = tab.data() + (size_t)p * bz::kPairTab;
+                    const int32_t *m = mem.data() + (size_t)p * n;
+                    for (int b = 0; b < 65536; ++b) {
+                        const uint32_t c = (uint32_t)(t[b + 1] - t[b]);
+                        tab8[(size_t)p * 65536 + b] = make_uint2(c, c == 1 ? (uint32_t)m[t[b]] : (uint32_t)t[b]);
+                    }
+                }
+                HIP_TRY(hipMalloc(&h->d_pair_tab8, tab8.size() * sizeof(uint2)));
+                HIP_TRY(hipMemcpy(h->d_pair_tab8, tab8.data(), tab8.size() * sizeof(uint2), hipMemcpyHostToDevice));
+                h->pair_cap = cap;
+            }
         }
     }
     h->n_wl = n;
@@ -530,7 +585,10 @@ int bz_assign_run(bz_handle h, int slot, int max_ed) {
         switch (max_ed) {
             case 0: if (seeded) launch_scan_seeded<0>(h, s); else if (filtered) launch_scan_filtered<0>(h, s); else launch_scan<0>(h, s); break;
             case 1: if (seeded) launch_scan_seeded<1>(h, s); else if (filtered) launch_scan_filtered<1>(h, s); else launch_scan<1>(h, s); break;
-            case 2: if (seeded && h->scan_mode == 0 && (s.stride & 15) == 0 && s.stride >= 32) launch_scan_paired(h, s); else if (seeded) launch_scan_seeded<2>(h, s);
+            case 2: if (seeded && h->scan_mode == 0 && (s.stride & 15) == 0 && s.stride >= 32) {
+                        if (h->pair_cap > 0 && !h->pair_fused) { if (int rc = launch_pair_two_kernels(h, s)) return rc; }
+                        else launch_scan_paired(h, s);
+                    } else if (seeded) launch_scan_seeded<2>(h, s);
                     else if (filtered) launch_scan_filtered<2>(h, s); else launch_scan<2>(h, s); break;
             default: launch_scan<3>(h, s); break;
         }

@@ -817,6 +817,225 @@ __global__ __launch_bounds__(kPairThreads) void k_scan_paired(
 }
 
 // ------------------------------------------------------------------------------------------
+// The same pair-seeded scan as two kernels (product path for max_ed == 2 while the candidate lists fit,
+// i.e. whitelists up to ~45k barcodes; above that k_scan_paired does both halves in one kernel):
+//
+//   k_pair_candidates : lane = row of the work list.  Needs the text's 2-bit codes only (2 VGPRs, no bit-plane
+//       masks), so 8 waves per SIMD hide the two dependent gathers per occupied bucket.  Probes the six LDS
+//       bitmaps, turns occupied buckets into barcode indices through `tab8` (entry = {count, only member or
+//       offset into members}: 96 % of the occupied buckets of a 5k list hold one barcode and need no second
+//       gather) and writes them to cand[s][slot] (s-th candidate of list slot `slot`: lanes of a wave write the
+//       same s at about the same time, so the 4-byte stores merge in L2 and k_pair_verify reads them coalesced).
+//   k_pair_verify<K>  : lane = row.  Two candidates per round through the packed K-error automaton; accepting
+//       candidates are only COLLECTED (distinct indices, <= kMaxEvents) and get their exact (ed, end) in a few
+//       rounds at the end (a true match is met through 3-6 pairs, and the divergent exact path used to run in
+//       almost every round of a wave); then the events are sorted by whitelist index and the reference's
+//       order-dependent fold is replayed.  Rows with more candidates than `cap` or more than kMaxEvents near
+//       matches go to redo_list (k_scan_filtered finishes them in whitelist order).
+constexpr int kCandThreads = 512;
+constexpr uint32_t kCandOverflow = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(kCandThreads) void k_pair_candidates(
+    const uint32_t *__restrict__ bitmap, const uint2 *__restrict__ tab8, const int32_t *__restrict__ members2, int n_wl,
+    const uint8_t *__restrict__ ext, int ext_stride, const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr,
+    uint32_t *__restrict__ cand, int cand_stride, int cap, uint32_t *__restrict__ cand_cnt) {
+    __shared__ uint32_t bm[kPairCount * kPairBmWords];
+    const int n_list = *n_list_ptr;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x * kCandThreads >= n_list) return;         // workgroup-uniform
+    for (int i = tid; i < kPairCount * kPairBmWords; i += kCandThreads) bm[i] = bitmap[i];
+    __syncthreads();
+    const int slot = blockIdx.x * kCandThreads + tid;
+    if ((slot & ~63) >= n_list) return;                           // whole wave idle
+    const bool active = slot < n_list;
+    const int r = list[active ? slot : n_list - 1];
+
+    uint64_t tc = 0;                                              // 2-bit codes of the text, column j at bits 2j
+    {
+        const RowBytes rb = load_row_packed(ext + (size_t)r * ext_stride);   // bytes past the text are zero: 'A' padding,
+#pragma unroll                                                               // which can only add candidates
+        for (int j = 0; j < kTextCols; ++j) tc |= (uint64_t)base_code(rb.at(j)) << (2 * j);
+    }
+    const uint32_t tlo_ = (uint32_t)tc, thi_ = (uint32_t)(tc >> 32);
+    uint32_t cnt = 0;
+    uint32_t *out = cand + slot;
+
+    auto do_pair = [&](auto pa_c, auto pb_c, auto p_c) {
+        constexpr int a = decltype(pa_c)::value, b = decltype(pb_c)::value, p = decltype(p_c)::value;
+        uint32_t mlo = 0, mhi = 0;                                // bit (5 xi + di) <=> windows (ja, jb) name an occupied bucket
+        const uint32_t tlo = in_vgpr(tlo_), thi = in_vgpr(thi_);  // opaque: no cross-pair hoisting of window codes
+#pragma unroll
+        for (int xi = 0; xi < 9; ++xi) {
+#pragma unroll
+            for (int di = 0; di < 5; ++di) {
+                const int ja = 4 * a - 2 + xi, jb = ja + 4 * (b - a) + di - 2;
+                const bool ok = ja >= 0 && ja + 4 <= kTextCols && jb >= 0 && jb + 4 <= kTextCols && !(b == a + 1 && di < 2);
+                if (ok) {
+                    const uint32_t ca = 2 * ja + 8 <= 32 ? (tlo >> (2 * ja)) : 2 * ja >= 32 ? (thi >> ((2 * ja) & 31)) : __builtin_amdgcn_alignbit(thi, tlo, (2 * ja) & 31);
+                    const uint32_t cb = 2 * jb + 8 <= 32 ? (tlo >> (2 * jb)) : 2 * jb >= 32 ? (thi >> ((2 * jb) & 31)) : __builtin_amdgcn_alignbit(thi, tlo, (2 * jb) & 31);
+                    const uint32_t key = ((ca & 0xFFu) << 8) | (cb & 0xFFu);
+                    const uint32_t w = bm[p * kPairBmWords + (key >> 5)];
+                    const uint32_t bit = (w >> (key & 31u)) & 1u;
+                    const int pos = 5 * xi + di;
+                    if (pos < 32) mlo |= bit << (pos & 31); else mhi |= bit << ((pos - 32) & 31);
+                }
+            }
+        }
+        if (!active) { mlo = 0; mhi = 0; }
+        const uint2 *tp = tab8 + (size_t)p * 65536;
+        const int32_t *mp = members2 + (size_t)p * n_wl;
+        const uint64_t tcc = ((uint64_t)thi << 32) | tlo;
+        while (__builtin_amdgcn_ballot_w64((mlo | mhi) != 0) != 0) {
+            uint2 e[kPairPop];                                    // straight-line: all look-ups of the step in flight together
+            bool h[kPairPop];
+#pragma unroll
+            for (int q = 0; q < kPairPop; ++q) {
+                const bool lo = mlo != 0;
+                const uint32_t w = lo ? mlo : mhi;
+                h[q] = w != 0;
+                const int pos = (int)__builtin_ctz(w | 0x80000000u) + (lo ? 0 : 32);
+                const uint32_t w2 = w & (w - 1u);
+                mlo = lo ? w2 : mlo;
+                mhi = lo ? mhi : w2;
+                const int xi = (pos * 13) >> 6, di = pos - 5 * xi;              // pos / 5, pos % 5 for pos < 64
+                const int ja = 4 * a - 2 + xi, jb = ja + 4 * (b - a) + di - 2;
+                const uint32_t key = (((uint32_t)(tcc >> ((2 * ja) & 63)) & 0xFFu) << 8) | ((uint32_t)(tcc >> ((2 * jb) & 63)) & 0xFFu);
+                e[q] = tp[h[q] ? key : 0u];
+            }
+#pragma unroll
+            for (int q = 0; q < kPairPop; ++q) {
+                const uint32_t n_mem = h[q] ? e[q].x : 0u;        // bucket size; e.y = the barcode (size 1) or the offset
+                if (n_mem == 1u) {
+                    if (cnt < (uint32_t)cap) out[(size_t)cnt * cand_stride] = e[q].y;
+                    ++cnt;
+                } else if (n_mem > 1u) {                          // rare for small whitelists
+                    for (uint32_t k = 0; k < n_mem; ++k) {
+                        if (cnt < (uint32_t)cap) out[(size_t)cnt * cand_stride] = (uint32_t)mp[e[q].y + k];
+                        ++cnt;
+                    }
+                }
+            }
+        }
+    };
+#define BZ_PAIR(A, B, P) do_pair(std::integral_constant<int, A>{}, std::integral_constant<int, B>{}, std::integral_constant<int, P>{})
+    BZ_PAIR(0, 1, 0); BZ_PAIR(0, 2, 1); BZ_PAIR(0, 3, 2); BZ_PAIR(1, 2, 3); BZ_PAIR(1, 3, 4); BZ_PAIR(2, 3, 5);
+#undef BZ_PAIR
+    if (active) cand_cnt[slot] = cnt > (uint32_t)cap ? kCandOverflow : cnt;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_pair_verify(
+    const uint32_t *__restrict__ cand, int cand_stride, const uint32_t *__restrict__ cand_cnt,
+    const uint32_t *__restrict__ planes32,
+    const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
+    const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int tie,
+    int32_t *__restrict__ redo_list, int32_t *__restrict__ n_redo,
+    int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
+    __shared__ uint32_t events[kMaxEvents][256];
+    const int n_list = *n_list_ptr;
+    const int tid = threadIdx.x;
+    const int slot = blockIdx.x * blockDim.x + tid;
+    if ((slot & ~63) >= n_list) return;                           // whole wave idle (wave-uniform)
+    const bool active = slot < n_list;
+    const int r = list[active ? slot : n_list - 1];
+    const int len = ext_len[r];
+    const uint32_t cnt_raw = active ? cand_cnt[slot] : 0u;
+    bool overflow = cnt_raw == kCandOverflow;
+    const uint32_t cnt = overflow ? 0u : cnt_raw;
+
+    uint32_t XH[kTextCols], XL[kTextCols];
+    {
+        const RowBytes rb = load_row_packed(ext + (size_t)r * ext_stride);
+#pragma unroll
+        for (int j = 0; j < kTextCols; ++j) {
+            const uint32_t c = (j < len) ? rb.at(j) : (uint32_t)'A';
+            const uint32_t code = base_code(c);
+            XH[j] = (code & 2u) ? 0u : 0xFFFFFFFFu;
+            XL[j] = (code & 1u) ? 0u : 0xFFFFFFFFu;
+        }
+    }
+    const uint32_t one = in_vgpr(kOne2);
+    constexpr int kFirst = kBcLen - K - 1;
+    int nacc = 0;                                                 // distinct accepted barcode indices in events[][tid]
+    const uint32_t *cp = cand + slot;
+
+    // candidates of round k: slots 2k and 2k+1 (an odd tail repeats the first); one round is prefetched
+    uint32_t i0 = 0, i1 = 0, p0 = 0, p1 = 0;
+    auto fetch = [&](uint32_t k, uint32_t &a0, uint32_t &a1, uint32_t &q0, uint32_t &q1) {
+        const bool v0 = 2 * k < cnt, v1 = 2 * k + 1 < cnt;
+        a0 = v0 ? cp[(size_t)(2 * k) * cand_stride] : 0u;
+        a1 = v1 ? cp[(size_t)(2 * k + 1) * cand_stride] : a0;
+        q0 = planes32[a0]; q1 = planes32[a1];
+    };
+    fetch(0, i0, i1, p0, p1);
+    for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(2 * k < cnt) != 0; ++k) {
+        const uint32_t c0 = i0, c1 = i1, q0 = p0, q1 = p1;
+        fetch(k + 1, i0, i1, p0, p1);                             // next round's loads fly under this round's automaton
+        const uint32_t bh = (q0 & 0xFFFFu) | (q1 << 16), bl = (q0 >> 16) | (q1 & 0xFFFF0000u);
+        PackedScan<K> A;
+        A.init();
+        uint32_t H = 0, P = 0;
+#pragma unroll
+        for (int j = 0; j < kTextCols; ++j) {
+            const uint32_t eq = BZ_LUT3(bh ^ XH[j], bl, XL[j], kTA & (kTB ^ kTC));
+            if (j == kTextCols - 1) A.template step<true>(eq, one);
+            else A.template step<false>(eq, one);
+            if (j >= kFirst) {
+                if (((j - kFirst) & 1) == 0) P = A.R[K];
+                else H = BZ_LUT3(H, P, A.R[K], kTA | kTB | kTC);
+            }
+        }
+        if (((kTextCols - 1 - kFirst) & 1) == 0) H |= P;
+        uint32_t acc = ((H >> 15) & 1u) | ((H >> 30) & 2u);
+        if (2 * k >= cnt) acc = 0;
+        if (2 * k + 1 >= cnt) acc &= 1u;
+        while (acc) {                                             // collect distinct accepted indices (cheap; exact path later)
+            const int b = __ffs(acc) - 1;
+            acc &= acc - 1;
+            const uint32_t idx = b ? c1 : c0;
+            bool seen = false;
+            for (int a = 0; a < nacc; ++a) seen = seen || events[a][tid] == idx;
+            if (!seen) {
+                if (nacc < kMaxEvents) events[nacc++][tid] = idx;
+                else overflow = true;
+            }
+        }
+    }
+    // exact (ed, end) of the accepted barcodes: a few wave-wide rounds
+    for (int a = 0; __builtin_amdgcn_ballot_w64(a < nacc) != 0; ++a) {
+        if (a < nacc) {
+            const uint32_t idx = events[a][tid];
+            const uint32_t p = planes32[idx];
+            int ed, end;
+            exact_pair<K>(p & 0xFFFFu, p >> 16, XH, XL, len, tie, ed, end);
+            events[a][tid] = ed <= K ? ((idx << 7) | ((uint32_t)ed << 5) | (uint32_t)end) : 0xFFFFFFFFu;   // rejected: sorts last
+        }
+    }
+    if (!active) return;
+    if (overflow) {                                               // too many candidates / near matches: finish in whitelist order
+        redo_list[atomicAdd(n_redo, 1)] = r;
+        return;
+    }
+    for (int a = 1; a < nacc; ++a) {                              // events in whitelist order (insertion sort)
+        const uint32_t v = events[a][tid];
+        int b = a - 1;
+        while (b >= 0 && events[b][tid] > v) { events[b + 1][tid] = events[b][tid]; --b; }
+        events[b + 1][tid] = v;
+    }
+    int best = K, hit = kHitNone, hit_end = -1;
+    bool done = false;
+    for (int a = 0; a < nacc; ++a) {
+        const uint32_t v = events[a][tid];
+        if (v == 0xFFFFFFFFu) break;
+        fold_update((int)((v >> 5) & 3u), (int)(v & 31u), (int)(v >> 7), best, hit, hit_end, done);
+    }
+    hit_out[r] = hit >= 0 ? hit : -1;
+    ed_out[r] = (int8_t)best;
+    end_out[r] = (int8_t)(hit >= 0 ? hit_end : -1);
+    flags_out[r] = (uint8_t)(hit == kHitAmbiguous ? kFlagAmbig : 0u);
+}
+
+// ------------------------------------------------------------------------------------------
 // Generic byte-wise semi-global DP (any alphabet, any lengths; pattern = the shorter operand,
 // the first one when equal).  Used for irregular rows / whitelists, max_ed > kMaxK and the
 // single-pair entry points.  D[0][j] = 0, D[i][0] = i, answer = min_j D[m][j], end = j-1.

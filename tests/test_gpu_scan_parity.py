@@ -11,11 +11,14 @@ from blaze_amd import _lib, synth
 pytestmark = pytest.mark.gpu
 
 FLAG_MASK = _lib.BZ_F_EXACT | _lib.BZ_F_BLANK | _lib.BZ_F_AMBIG
+FUSED = 4          # scan mode 0 with BZ_OPT_PAIR_FUSED: the one-kernel form of the pair-seeded scan
+MODES = dict(argvalues=[0, 1, 2, 3, FUSED], ids=["seeded", "bruteforce", "filtered", "seeded3", "fused"])
 
 
 def _compare(engine, oracle, ext, el, bo, bl, wl, max_ed, tie=0, shortcut=True, force_generic=False, threads=8,
              scan_mode=0):
-    engine.set_option(_lib.BZ_OPT_SCAN_MODE, scan_mode)
+    engine.set_option(_lib.BZ_OPT_SCAN_MODE, 0 if scan_mode == FUSED else scan_mode)
+    engine.set_option(_lib.BZ_OPT_PAIR_FUSED, int(scan_mode == FUSED))
     engine.set_option(_lib.BZ_OPT_TIE_RULE, tie)
     engine.set_option(_lib.BZ_OPT_SHORTCUT, int(shortcut))
     engine.set_option(_lib.BZ_OPT_FORCE_GENERIC, int(force_generic))
@@ -26,6 +29,7 @@ def _compare(engine, oracle, ext, el, bo, bl, wl, max_ed, tie=0, shortcut=True, 
     engine.set_option(_lib.BZ_OPT_SHORTCUT, 1)
     engine.set_option(_lib.BZ_OPT_FORCE_GENERIC, 0)
     engine.set_option(_lib.BZ_OPT_SCAN_MODE, 0)
+    engine.set_option(_lib.BZ_OPT_PAIR_FUSED, 0)
     bad = np.flatnonzero((hit != o_hit) | (ed != o_ed) | (end != o_end) | ((flags & FLAG_MASK) != o_flag))
     assert bad.size == 0, (
         f"{bad.size} rows differ, first {bad[0]}: ext={bytes(ext[bad[0], :el[bad[0]]])!r} "
@@ -42,7 +46,7 @@ def _synthetic(n_rows, n_cells, err=1.0, seed=3, umi_len=12):
     return rows, synth.codes_to_bytes(cells)
 
 
-@pytest.mark.parametrize("scan_mode", [0, 1, 2], ids=["seeded", "bruteforce", "filtered"])
+@pytest.mark.parametrize("scan_mode", **MODES)
 @pytest.mark.parametrize("max_ed", [0, 1, 2, 3])
 @pytest.mark.parametrize("tie", [0, 1])
 def test_bitparallel_vs_oracle(engine, oracle, max_ed, tie, scan_mode):
@@ -55,7 +59,7 @@ def test_bitparallel_vs_oracle(engine, oracle, max_ed, tie, scan_mode):
     assert (hit >= 0).sum() > 1000
 
 
-@pytest.mark.parametrize("scan_mode", [0, 1, 2], ids=["seeded", "bruteforce", "filtered"])
+@pytest.mark.parametrize("scan_mode", **MODES)
 def test_all_rows_scored_mode(engine, oracle, scan_mode):
     rows, wl = _synthetic(4000, 333, err=2.0, seed=7)        # odd whitelist size: exercises the padding
     ext, el, bo, bl = synth.pack_ext(rows)
@@ -157,7 +161,7 @@ def test_near_duplicate_whitelist_order_dependence(engine, oracle):
         np.random.default_rng(seed).shuffle(order)
         for tie in (0, 1):
             hit, *_ = _compare(engine, oracle, ext, el, bo, bl, order, 2, tie=tie)
-            for mode in (1, 2):
+            for mode in (1, 2, 3, FUSED):
                 hit_b, *_ = _compare(engine, oracle, ext, el, bo, bl, order, 2, tie=tie, scan_mode=mode)
                 assert np.array_equal(hit, hit_b)
         assert engine.timing(0)["rows_redo"] >= 0
@@ -189,9 +193,9 @@ def test_low_complexity_whitelist_fills_the_candidate_fifo(engine, oracle):
     redo = 0
     for max_ed in (1, 2):
         for shortcut in (True, False):
-            for mode in (0, 2):
+            for mode in (0, 2, 3, FUSED):
                 _compare(engine, oracle, ext, el, bo, bl, wl, max_ed, shortcut=shortcut, scan_mode=mode)
-                if mode == 0:
+                if mode in (0, 3, FUSED):
                     redo += engine.timing(0)["rows_redo"]
     assert redo > 0, "expected rows with more than 8 near matches (seeded scan hands them to the filtered scan)"
 
@@ -203,10 +207,12 @@ def test_seeded_filtered_bruteforce_agree_large(engine):
     ext, el, bo, bl = synth.pack_ext(rows)
     engine.set_whitelist_codes16(wl)
     a = engine.assign(ext, el, bo, bl, 2)
-    for mode in (1, 2):
-        engine.set_option(_lib.BZ_OPT_SCAN_MODE, mode)
+    for mode in (1, 2, 3, FUSED):
+        engine.set_option(_lib.BZ_OPT_SCAN_MODE, 0 if mode == FUSED else mode)
+        engine.set_option(_lib.BZ_OPT_PAIR_FUSED, int(mode == FUSED))
         b = engine.assign(ext, el, bo, bl, 2)
         engine.set_option(_lib.BZ_OPT_SCAN_MODE, 0)
+        engine.set_option(_lib.BZ_OPT_PAIR_FUSED, 0)
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
     assert (a[0] >= 0).sum() > 60_000
@@ -250,3 +256,41 @@ def test_counts_histogram(engine, oracle):
     expect = np.bincount(hit[hit >= 0], minlength=100) + np.bincount(hit2[hit2 >= 0], minlength=100)
     assert np.array_equal(c[:100], expect)
     assert c[100] == (hit >= 0).sum() + (hit2 >= 0).sum() and c[101] == 6000
+
+
+@pytest.mark.parametrize("scan_mode", **MODES)
+def test_barcode_anywhere_in_the_text(engine, oracle, scan_mode):
+    """The seeds' window ranges at their limits: a whitelist barcode with 0-2 random edit operations placed at EVERY
+    offset of a 16-20 nt text (the reference's scan is semi-global: `sub_edit_distance` finds it wherever it sits),
+    with flanks drawn from the barcode's own bases so that shifted alignments tie."""
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    wl = [acgt[rng.integers(0, 4, 16)].tobytes() for _ in range(400)]
+    wl = list(dict.fromkeys(wl))
+    n = 12000
+    ext = np.zeros((n, 32), dtype=np.uint8)
+    el = np.zeros(n, np.uint8)
+    for r in range(n):
+        w = list(np.frombuffer(wl[rng.integers(0, len(wl))], dtype=np.uint8))
+        for _ in range(int(rng.integers(0, 3))):                  # 0-2 edit operations
+            op, pos = rng.integers(0, 3), int(rng.integers(0, len(w)))
+            if op == 0:
+                w[pos] = acgt[rng.integers(0, 4)]
+            elif op == 1:
+                del w[pos]
+            else:
+                w.insert(pos, acgt[rng.integers(0, 4)])
+        length = int(rng.integers(max(16, len(w)), 21))
+        start = int(rng.integers(0, length - len(w) + 1))
+        text = acgt[rng.integers(0, 4, length)].copy()
+        if r % 3 == 0:                                            # low-complexity flanks: many tied alignments
+            text[:] = w[0]
+        text[start:start + len(w)] = w
+        ext[r, :length] = text
+        el[r] = length
+    bo = np.minimum(2, el - 16).astype(np.uint8)
+    bl = np.full(n, 16, np.uint8)
+    for max_ed in ((2,) if scan_mode in (3, FUSED) else (0, 1, 2, 3)):
+        for tie in (0, 1):
+            hit, ed, *_ = _compare(engine, oracle, ext, el, bo, bl, wl, max_ed, tie=tie, shortcut=False, scan_mode=scan_mode)
+    assert (hit >= 0).sum() > n // 2

@@ -16,7 +16,7 @@ eng = Engine(0)
 ops, ms = eng.valu_peak_probe(20000)
 print(f"valu probe: {ops/1e12:.2f} T lane-ops/s ({ms:.2f} ms)")
 eng.set_whitelist_codes16(synth.codes_to_bytes(cells))
-for shortcut, mode in ((1, 0), (0, 0), (1, 3), (0, 3), (1, 2), (0, 2)):
+for shortcut, mode in ((1, 0), (0, 0), (1, 3), (0, 3)):
     eng.set_option(_lib.BZ_OPT_SHORTCUT, shortcut)
     eng.set_option(_lib.BZ_OPT_SCAN_MODE, mode)
     eng.stage(0, ext, el, bo, bl)

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libblaze_hip.so")
 
-BZ_OPT_TIE_RULE, BZ_OPT_SHORTCUT, BZ_OPT_FORCE_GENERIC, BZ_OPT_SCAN_MODE, BZ_OPT_PAIR_FUSED = 1, 2, 3, 4, 5
+BZ_OPT_TIE_RULE, BZ_OPT_SHORTCUT, BZ_OPT_FORCE_GENERIC, BZ_OPT_SCAN_MODE, BZ_OPT_PAIR_FUSED, BZ_OPT_PROFILE = 1, 2, 3, 4, 5, 6
 BZ_F_EXACT, BZ_F_BLANK, BZ_F_AMBIG, BZ_F_GENERIC = 1, 2, 4, 8
 BZ_EXT_MAX = 64
 BZ_E_MISMATCH = -6

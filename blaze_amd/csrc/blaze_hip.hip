@@ -90,14 +90,16 @@ struct Slot {
     int cand_stride = 0;
     // pinned host staging
     uint8_t *h_in = nullptr, *h_out = nullptr;
-    int32_t *h_counters = nullptr;
+    int32_t *h_counters = nullptr, *h_counters_dev = nullptr;   // pinned + mapped: the last kernel of a run writes it
+    int32_t *d_counters_base = nullptr;   // two sets of 4; d_counters points at the set of the current run
+    bool timed = false;
 };
 
 }  // namespace
 
 struct bz_engine {
     int device = 0;
-    int tie_rule = 0, shortcut = 1, force_generic = 0, scan_mode = 0, pair_fused = 0;
+    int tie_rule = 0, shortcut = 1, force_generic = 0, scan_mode = 0, pair_fused = 0, profile = 0;
     // whitelist
     int64_t n_wl = -1;
     int wl_regular = 0;
@@ -120,6 +122,7 @@ struct bz_engine {
     uint8_t *d_wl_bytes = nullptr;
     int64_t *d_wl_off = nullptr;
     unsigned long long *d_counts = nullptr;
+    uint32_t *d_hist_partial = nullptr;   // kHistBlocks x n_wl private histograms (whitelists up to kHistLdsBins), else null
     Slot slot[BZ_SLOTS];
     std::vector<char> wl_host;         // host copy of the whitelist (bz_assign_files writes barcodes from it)
     std::vector<int64_t> wl_off_host;
@@ -141,7 +144,8 @@ int use(bz_handle h) {
 
 void free_whitelist(bz_handle h) {
     hipFree(h->d_planes); hipFree(h->d_sorted_codes); hipFree(h->d_sorted_idx);
-    hipFree(h->d_wl_bytes); hipFree(h->d_wl_off); hipFree(h->d_counts);
+    hipFree(h->d_wl_bytes); hipFree(h->d_wl_off); hipFree(h->d_counts); hipFree(h->d_hist_partial);
+    h->d_hist_partial = nullptr;
     hipFree(h->d_grams); hipFree(h->d_planes32); hipFree(h->d_bucket);
     h->d_grams = nullptr; h->d_planes32 = nullptr; h->d_bucket = nullptr;
     for (int k = 0; k < 2; ++k) {
@@ -309,12 +313,18 @@ int bz_create(int device, bz_handle *out) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         h->n_cu = std::max(1, prop.multiProcessorCount);
+        HIP_TRY(hipFuncSetAttribute((const void *)bz::k_hist_partial, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)((bz::kHistLdsBins + 1) * sizeof(uint32_t))));
     }
     for (Slot &s : h->slot) {
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         for (hipEvent_t &e : s.ev) HIP_TRY(hipEventCreate(&e));
-        HIP_TRY(hipMalloc(&s.d_counters, 4 * sizeof(int32_t)));
-        HIP_TRY(hipHostMalloc(&s.h_counters, 4 * sizeof(int32_t), hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&s.d_counters_base, 8 * sizeof(int32_t)));
+        HIP_TRY(hipMemset(s.d_counters_base, 0, 8 * sizeof(int32_t)));
+        s.d_counters = s.d_counters_base;
+        HIP_TRY(hipHostMalloc(&s.h_counters, 4 * sizeof(int32_t), hipHostMallocMapped));
+        memset(s.h_counters, 0, 4 * sizeof(int32_t));
+        HIP_TRY(hipHostGetDevicePointer((void **)&s.h_counters_dev, s.h_counters, 0));
     }
     HIP_TRY(hipMalloc(&h->d_pair, 4096));
     HIP_TRY(hipMalloc(&h->d_pair_out, 2 * sizeof(int32_t)));
@@ -331,7 +341,7 @@ int bz_destroy(bz_handle h) {
     free_whitelist(h);
     for (Slot &s : h->slot) {
         free_slot(s);
-        hipFree(s.d_counters); hipHostFree(s.h_counters);
+        hipFree(s.d_counters_base); hipHostFree(s.h_counters);
         for (hipEvent_t &e : s.ev) if (e) hipEventDestroy(e);
         if (s.stream) hipStreamDestroy(s.stream);
     }
@@ -348,6 +358,7 @@ int bz_set_option(bz_handle h, int option, int64_t value) {
         case BZ_OPT_FORCE_GENERIC: h->force_generic = value ? 1 : 0; return BZ_OK;
         case BZ_OPT_SCAN_MODE: if (value < 0 || value > 3) return fail(BZ_E_ARG, "scan mode must be 0..3"); h->scan_mode = (int)value; return BZ_OK;
         case BZ_OPT_PAIR_FUSED: h->pair_fused = value ? 1 : 0; return BZ_OK;
+        case BZ_OPT_PROFILE: h->profile = value ? 1 : 0; return BZ_OK;
     }
     return fail(BZ_E_ARG, "unknown option %d", option);
 }
@@ -378,6 +389,7 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
     HIP_TRY(hipMemcpy(h->d_wl_off, off.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&h->d_counts, counts_bytes(n)));
     HIP_TRY(hipMemset(h->d_counts, 0, counts_bytes(n)));
+    if (n > 0 && n <= bz::kHistLdsBins) HIP_TRY(hipMalloc(&h->d_hist_partial, (size_t)bz::kHistBlocks * n * sizeof(uint32_t)));
 
     h->wl_host.assign(bytes + (n ? offsets[0] : 0), bytes + (n ? offsets[0] : 0) + total);
     h->wl_off_host = off;
@@ -566,15 +578,19 @@ int bz_assign_run(bz_handle h, int slot, int max_ed) {
     if (!s.staged) return fail(BZ_E_STATE, "slot %d has no staged rows", slot);
     if (max_ed < 0 || max_ed > BZ_EXT_MAX) return fail(BZ_E_ARG, "max_ed %d outside 0..%d", max_ed, BZ_EXT_MAX);
     const int n = (int)s.n;
-    HIP_TRY(hipEventRecord(s.ev[0], s.stream));
-    HIP_TRY(hipMemsetAsync(s.d_counters, 0, 4 * sizeof(int32_t), s.stream));
+    // HIP events between the kernels cost ~6 us of idle GPU each: recorded only when BZ_OPT_PROFILE is on
+    const bool prof = h->profile != 0;
+    s.timed = prof;
+    if (n == 0) { memset(s.h_counters, 0, 4 * sizeof(int32_t)); s.timed = false; s.ran = true; return BZ_OK; }
+    int32_t *const next_counters = s.d_counters_base + (s.d_counters == s.d_counters_base ? 4 : 0);
+    if (prof) HIP_TRY(hipEventRecord(s.ev[0], s.stream));
     if (n) {
         hipLaunchKernelGGL(bz::k_classify, dim3((n + 256 * bz::kClassifyRows - 1) / (256 * bz::kClassifyRows)), dim3(256), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
                            s.d_bcl, n, h->wl_regular, h->d_sorted_codes, h->d_sorted_idx, (int)h->n_wl, h->d_bucket, h->bucket_bits, h->shortcut,
                            h->force_generic, max_ed, s.d_fast, s.d_gen, s.d_counters, s.d_hit, s.d_ed, s.d_end, s.d_flags);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(s.ev[1], s.stream));
+    if (prof) HIP_TRY(hipEventRecord(s.ev[1], s.stream));
     if (n && h->wl_regular && !h->force_generic && max_ed <= bz::kMaxK) {
         // product path for max_ed <= 2: pigeonhole seeds + verify (BZ_OPT_SCAN_MODE 0); mode 2 = exact 3-gram
         // filter + verify over the whole whitelist; mode 1 = brute force (also what max_ed 3 takes: its
@@ -594,20 +610,28 @@ int bz_assign_run(bz_handle h, int slot, int max_ed) {
         }
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(s.ev[2], s.stream));
+    if (prof) HIP_TRY(hipEventRecord(s.ev[2], s.stream));
     if (n) {
-        hipLaunchKernelGGL(bz::k_scan_generic, dim3((n + 63) / 64), dim3(64), 0, s.stream, h->d_wl_bytes, h->d_wl_off, (int)h->n_wl,
+        hipLaunchKernelGGL(bz::k_scan_generic, dim3(std::min((n + 63) / 64, 16 * h->n_cu)), dim3(64), 0, s.stream, h->d_wl_bytes, h->d_wl_off, (int)h->n_wl,
                            s.d_ext, s.stride, s.d_len, s.d_off, s.d_bcl, s.d_gen, s.d_counters + 1, max_ed, h->tie_rule,
                            h->shortcut, s.d_hit, s.d_ed, s.d_end, s.d_flags);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(s.ev[3], s.stream));
+    if (prof) HIP_TRY(hipEventRecord(s.ev[3], s.stream));
     if (n) {
-        hipLaunchKernelGGL(bz::k_histogram, dim3(std::min((n + 255) / 256, 1024)), dim3(256), 0, s.stream, s.d_hit, n, (int)h->n_wl, h->d_counts);
+        if (h->d_hist_partial) {
+            hipLaunchKernelGGL(bz::k_hist_partial, dim3(bz::kHistBlocks), dim3(bz::kHistThreads), (size_t)(h->n_wl + 1) * sizeof(uint32_t), s.stream,
+                               s.d_hit, n, (int)h->n_wl, h->d_hist_partial, h->d_counts);
+            hipLaunchKernelGGL(bz::k_hist_reduce, dim3(((int)h->n_wl + 255) / 256), dim3(256), 0, s.stream, h->d_hist_partial, (int)h->n_wl, h->d_counts,
+                               s.d_counters, next_counters, s.h_counters_dev);
+        } else {
+            hipLaunchKernelGGL(bz::k_histogram, dim3(std::min((n + 255) / 256, 1024)), dim3(256), 0, s.stream, s.d_hit, n, (int)h->n_wl, h->d_counts,
+                               s.d_counters, next_counters, s.h_counters_dev);
+        }
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipMemcpyAsync(s.h_counters, s.d_counters, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
-    HIP_TRY(hipEventRecord(s.ev[4], s.stream));
+    s.d_counters = next_counters;
+    if (prof) HIP_TRY(hipEventRecord(s.ev[4], s.stream));
     s.ran = true;
     return BZ_OK;
 }
@@ -672,8 +696,10 @@ int bz_slot_timing(bz_handle h, int slot, float ms[8], int64_t counts[8]) {
     HIP_TRY(hipStreamSynchronize(s.stream));
     if (ms) {
         memset(ms, 0, 8 * sizeof(float));
-        HIP_TRY(hipEventElapsedTime(&ms[0], s.ev[0], s.ev[4]));
-        for (int i = 1; i <= 4; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], s.ev[i - 1], s.ev[i]));
+        if (s.timed) {                                  // BZ_OPT_PROFILE was on for that run
+            HIP_TRY(hipEventElapsedTime(&ms[0], s.ev[0], s.ev[4]));
+            for (int i = 1; i <= 4; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], s.ev[i - 1], s.ev[i]));
+        }
     }
     if (counts) {
         memset(counts, 0, 8 * sizeof(int64_t));

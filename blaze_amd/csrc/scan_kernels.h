@@ -1099,12 +1099,12 @@ __global__ void k_scan_generic(const uint8_t *__restrict__ wl_bytes, const int64
                                int shortcut, int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out,
                                int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
     const int n_list = *n_list_ptr;
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= n_list) return;
+    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_list; slot += gridDim.x * blockDim.x) {   // small persistent grid
     const int r = list[slot];
     const uint8_t *row = ext + (size_t)r * ext_stride;
     const int len = ext_len[r], off = bc_off[r], bl = bc_len[r];
 
+    bool exact = false;
     if (shortcut) {                                           // `row.putative_bc in whitelist` (:61)
         for (int k = 0; k < n_wl; ++k) {
             const int64_t o = wl_off[k];
@@ -1113,10 +1113,12 @@ __global__ void k_scan_generic(const uint8_t *__restrict__ wl_bytes, const int64
             for (int i = 0; i < bl && same; ++i) same = wl_bytes[o + i] == row[off + i];
             if (same) {
                 hit_out[r] = k; ed_out[r] = 0; end_out[r] = -1; flags_out[r] = (uint8_t)(kFlagExact | kFlagGeneric);
-                return;
+                exact = true;
+                break;
             }
         }
     }
+    if (exact) continue;
     int best = max_ed, hit = kHitNone, hit_end = -1;
     bool hit_empty = false;                                   // bc_hit is the empty string (falsy in Python)
     bool done = false;
@@ -1136,6 +1138,7 @@ __global__ void k_scan_generic(const uint8_t *__restrict__ wl_bytes, const int64
     ed_out[r] = (int8_t)best;
     end_out[r] = (int8_t)(ok ? hit_end : -1);
     flags_out[r] = (uint8_t)(kFlagGeneric | (hit == kHitAmbiguous ? kFlagAmbig : 0u));
+    }
 }
 
 __global__ void k_pair(const uint8_t *a, int la, const uint8_t *b, int lb, int max_ed, int tie, int global_mode, int32_t *out) {
@@ -1149,6 +1152,7 @@ __global__ void k_pair(const uint8_t *a, int la, const uint8_t *b, int lb, int m
 // `row.putative_bc in whitelist` = look-up of the 2-bit code in the sorted whitelist: a bucket table
 // over the code's top `bucket_bits` bits gives the (short) range, a lower-bound search inside it the
 // entry (duplicates -> first index in caller order).  2-3 dependent loads instead of log2(n_wl).
+constexpr int kTotStripes = 64;
 constexpr int kClassifyRows = 4;                              // rows per thread: 1024 per workgroup, ONE list atomic pair per workgroup
 
 __global__ __launch_bounds__(256) void k_classify(
@@ -1224,13 +1228,75 @@ __global__ __launch_bounds__(256) void k_classify(
     }
 }
 
-// counts[hit] += 1 for assigned rows; the two totals (assigned, rows) go to kTotStripes striped
-// slots behind counts[n_wl + 2] (one atomic pair per workgroup, 16 per address per 1024-block
-// launch) and are folded into counts[n_wl], counts[n_wl+1] by k_fold_totals before anyone reads them.
-constexpr int kTotStripes = 64;
+// Totals: [assigned, rows seen] go to kTotStripes striped slots behind counts[n_wl + 2] (one atomic pair per
+// workgroup) and are folded into counts[n_wl], counts[n_wl+1] by k_fold_totals before anyone reads them.
+// Per-barcode counts of one run.  Two forms:
+//  * whitelists up to kHistLdsBins barcodes: kHistBlocks workgroups each keep a private histogram of ALL bins in LDS
+//    (ds_add, no global atomics), write it to partial[block][bin], and k_hist_reduce adds the partials into counts[]
+//    (one owner per bin).  Global atomics from 8 XCDs on a 40 KB table ran at ~13 G/s = 55 us per 1M rows; this form
+//    takes a pass over hit[] at streaming rate.
+//  * larger whitelists: one global atomic per assigned row (no contention to speak of on millions of bins).
+// Both add [assigned, rows seen] to the striped totals.
+constexpr int kHistLdsBins = 32768;
+constexpr int kHistBlocks = 64;
+constexpr int kHistThreads = 1024;
+
+__global__ __launch_bounds__(kHistThreads) void k_hist_partial(const int32_t *__restrict__ hit, int n, int n_wl,
+                                                              uint32_t *__restrict__ partial, unsigned long long *__restrict__ counts) {
+    extern __shared__ uint32_t s_bins[];                          // n_wl bins + 1 (assigned)
+    for (int b = threadIdx.x; b <= n_wl; b += kHistThreads) s_bins[b] = 0;
+    __syncthreads();
+    const int per = (((n + kHistBlocks - 1) / kHistBlocks) + 3) & ~3;     // rows per block, multiple of 4 (16-byte loads)
+    const int lo = blockIdx.x * per, hi = min(n, lo + per);
+    int assigned = 0;
+    for (int i = lo + 4 * threadIdx.x; i < hi; i += 4 * kHistThreads) {
+        if (i + 4 <= hi) {
+            const int4 h = *(const int4 *)(hit + i);
+            if (h.x >= 0) { atomicAdd(&s_bins[h.x], 1u); ++assigned; }
+            if (h.y >= 0) { atomicAdd(&s_bins[h.y], 1u); ++assigned; }
+            if (h.z >= 0) { atomicAdd(&s_bins[h.z], 1u); ++assigned; }
+            if (h.w >= 0) { atomicAdd(&s_bins[h.w], 1u); ++assigned; }
+        } else {
+            for (int k = i; k < hi; ++k) { const int h = hit[k]; if (h >= 0) { atomicAdd(&s_bins[h], 1u); ++assigned; } }
+        }
+    }
+    if (assigned) atomicAdd(&s_bins[n_wl], (uint32_t)assigned);
+    __syncthreads();
+    uint32_t *out = partial + (size_t)blockIdx.x * n_wl;
+    for (int b = threadIdx.x; b < n_wl; b += kHistThreads) out[b] = s_bins[b];
+    if (threadIdx.x == 0) {
+        unsigned long long *tot = counts + n_wl + 2 + 2 * (blockIdx.x & (kTotStripes - 1));
+        if (s_bins[n_wl]) atomicAdd(&tot[0], (unsigned long long)s_bins[n_wl]);
+        if (hi > lo) atomicAdd(&tot[1], (unsigned long long)(hi - lo));
+    }
+}
+
+// End-of-run duties of the last kernel of a run: publish the run's list counters to the (host-mapped) pinned
+// buffer the timing call reads, and zero the OTHER counter set, which the next run on this slot will use
+// (so a run needs neither a memset nor a device-to-host copy dispatch).
+__device__ __forceinline__ void finish_run(const int32_t *cur, int32_t *next, int32_t *host_out) {
+    if (blockIdx.x == 0 && threadIdx.x < 4) { host_out[threadIdx.x] = cur[threadIdx.x]; next[threadIdx.x] = 0; }
+}
+
+__global__ __launch_bounds__(256) void k_hist_reduce(const uint32_t *__restrict__ partial, int n_wl, unsigned long long *__restrict__ counts,
+                                                    const int32_t *cur, int32_t *next, int32_t *host_out) {
+    finish_run(cur, next, host_out);
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_wl) return;
+    uint32_t v[kHistBlocks];
+#pragma unroll
+    for (int k = 0; k < kHistBlocks; ++k) v[k] = partial[(size_t)k * n_wl + b];   // all loads in flight: one latency
+    unsigned long long s = 0;
+#pragma unroll
+    for (int k = 0; k < kHistBlocks; ++k) s += v[k];
+    if (s) counts[b] += s;
+}
+
 __global__ __launch_bounds__(256) void k_histogram(const int32_t *__restrict__ hit, int n, int n_wl,
-                                                  unsigned long long *__restrict__ counts) {
+                                                  unsigned long long *__restrict__ counts,
+                                                  const int32_t *cur, int32_t *next, int32_t *host_out) {
     __shared__ unsigned int s_assigned[4];
+    finish_run(cur, next, host_out);
     int assigned = 0;
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
         const int h = hit[r];

@@ -61,6 +61,9 @@ typedef struct bz_engine *bz_handle;
 #define BZ_OPT_PAIR_FUSED 5    /* 1 = run the pair-seeded scan of mode 0 as ONE kernel (k_scan_paired) even when the
                                   whitelist is small enough for the two-kernel form (testing; results identical) */
 
+#define BZ_OPT_PROFILE 6       /* 1 = record HIP events between the kernels of every run (bz_slot_timing's ms[]); off by
+                                  default: each event costs ~6 us of idle GPU between two kernels */
+
 /* result flags (per row) */
 #define BZ_F_EXACT 1u      /* took the exact-match shortcut */
 #define BZ_F_BLANK 2u      /* empty putative_bc (`not row.putative_bc`, read_assignment.py:61) */
@@ -108,7 +111,7 @@ int bz_assign_stage(bz_handle h, int slot, const uint8_t *ext, int ext_stride, c
 int bz_assign_run(bz_handle h, int slot, int max_ed);
 int bz_assign_fetch(bz_handle h, int slot, int32_t *hit, int8_t *ed, int8_t *end_idx, uint8_t *flags);
 int bz_slot_sync(bz_handle h, int slot);
-/* HIP-event durations (ms) of the slot's last run: ms[0] whole run, [1] classify+shortcut,
+/* HIP-event durations (ms) of the slot's last run (zeros unless BZ_OPT_PROFILE was on): ms[0] whole run, [1] classify+shortcut,
  * [2] bit-parallel scan, [3] generic scan, [4] histogram; counts[0] rows, [1] rows scored by the
  * bit-parallel kernels, [2] rows scored by the generic kernel, [3] whitelist size, [4] rows the seeded
  * scan handed to the filtered scan (more than 8 near matches). */

@@ -16,11 +16,19 @@ eng = Engine(0)
 ops, ms = eng.valu_peak_probe(20000)
 print(f"valu probe: {ops/1e12:.2f} T lane-ops/s ({ms:.2f} ms)")
 eng.set_whitelist_codes16(synth.codes_to_bytes(cells))
+import os as _os
+eng.set_option(_lib.BZ_OPT_PROFILE, int(_os.environ.get('BZ_PROFILE', '1')))
 for shortcut, mode in ((1, 0), (0, 0), (1, 3), (0, 3)):
     eng.set_option(_lib.BZ_OPT_SHORTCUT, shortcut)
     eng.set_option(_lib.BZ_OPT_SCAN_MODE, mode)
     eng.stage(0, ext, el, bo, bl)
-    for rep in range(3):
+    eng.run(0, 2); eng.sync(0)
+    t0 = time.time()
+    for rep in range(20):
+        eng.run(0, 2)
+    eng.sync(0)
+    print(f"mode={mode} shortcut={shortcut}: 20 back-to-back runs {(time.time() - t0) / 20 * 1e3:.3f} ms each")
+    for rep in range(2):
         t0 = time.time(); eng.run(0, 2); eng.sync(0); wall = time.time() - t0
         t = eng.timing(0)
         pairs = t["rows_bitparallel"] * n_wl

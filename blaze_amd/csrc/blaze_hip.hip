@@ -230,15 +230,15 @@ void launch_scan_seeded(bz_handle h, Slot &s) {
 // pair-seeded scan, two-kernel form (whitelists whose candidate lists fit `pair_cap` slots per row)
 int launch_pair_two_kernels(bz_handle h, Slot &s) {
     const int stride = (int)((s.n + 63) / 64 * 64);
-    const int64_t need = (int64_t)h->pair_cap * stride;
+    const int64_t need = (int64_t)(h->pair_cap + 1) * stride;
     if (need > s.cand_words || !s.d_cand_cnt) {
         HIP_TRY(hipStreamSynchronize(s.stream));
         hipFree(s.d_cand); hipFree(s.d_cand_cnt);
         s.d_cand = s.d_cand_cnt = nullptr; s.cand_words = 0;
         const int64_t rows = std::max<int64_t>(s.cap, stride);
-        HIP_TRY(hipMalloc(&s.d_cand, (size_t)h->pair_cap * rows * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&s.d_cand, (size_t)(h->pair_cap + 1) * rows * sizeof(uint32_t)));   // + the dump row
         HIP_TRY(hipMalloc(&s.d_cand_cnt, (size_t)rows * sizeof(uint32_t)));
-        s.cand_words = (int64_t)h->pair_cap * rows;
+        s.cand_words = (int64_t)(h->pair_cap + 1) * rows;
     }
     s.cand_stride = stride;
     const int ga = (int)((s.n + bz::kCandThreads - 1) / bz::kCandThreads);
@@ -527,8 +527,8 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
                     const int32_t *t = tab.data() + (size_t)p * bz::kPairTab;
                     const int32_t *m = mem.data() + (size_t)p * n;
                     for (int b = 0; b < 65536; ++b) {
-                        const uint32_t c = (uint32_t)(t[b + 1] - t[b]);
-                        tab8[(size_t)p * 65536 + b] = make_uint2(c, c == 1 ? (uint32_t)m[t[b]] : (uint32_t)t[b]);
+                        const uint32_t c = (uint32_t)(t[b + 1] - t[b]);       // {size (saturating) | offset << 8, first member}
+                        tab8[(size_t)p * 65536 + b] = make_uint2(std::min(c, 255u) | ((uint32_t)t[b] << 8), c ? (uint32_t)m[t[b]] : 0u);
                     }
                 }
                 HIP_TRY(hipMalloc(&h->d_pair_tab8, tab8.size() * sizeof(uint2)));

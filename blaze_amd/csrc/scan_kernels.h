@@ -824,7 +824,7 @@ __global__ __launch_bounds__(kPairThreads) void k_scan_paired(
 //       masks), so 8 waves per SIMD hide the two dependent gathers per occupied bucket.  Probes the six LDS
 //       bitmaps, turns occupied buckets into barcode indices through `tab8` (entry = {count, only member or
 //       offset into members}: 96 % of the occupied buckets of a 5k list hold one barcode and need no second
-//       gather) and writes them to cand[s][slot] (s-th candidate of list slot `slot`: lanes of a wave write the
+//       gather; entry = {size | offset << 8, first member}) and writes them to cand[s][slot] (s-th candidate of list slot `slot`: lanes of a wave write the
 //       same s at about the same time, so the 4-byte stores merge in L2 and k_pair_verify reads them coalesced).
 //   k_pair_verify<K>  : lane = row.  Two candidates per round through the packed K-error automaton; accepting
 //       candidates are only COLLECTED (distinct indices, <= kMaxEvents) and get their exact (ed, end) in a few
@@ -832,9 +832,14 @@ __global__ __launch_bounds__(kPairThreads) void k_scan_paired(
 //       almost every round of a wave); then the events are sorted by whitelist index and the reference's
 //       order-dependent fold is replayed.  Rows with more candidates than `cap` or more than kMaxEvents near
 //       matches go to redo_list (k_scan_filtered finishes them in whitelist order).
-constexpr int kCandThreads = 512;
 constexpr uint32_t kCandOverflow = 0xFFFFFFFFu;
+constexpr int kCandThreads = 1024;
+constexpr int kCandPop = 8;                                       // hits decoded per lane and pair in the straight-line part
 
+// lane = row.  Straight-line per pair: 27 bitmap probes -> up to kCandPop hits popped -> their bucket look-ups ISSUED;
+// the look-ups of the previous pair are CONSUMED only after that, so a wave always has one pair's gathers in flight
+// while it probes the next (the first version waited on every step of every pair: 63 us at 4.5 waves per SIMD with
+// nothing saturated).  Lanes with more than kCandPop hits in one pair (rare) finish them in a small loop.
 __global__ __launch_bounds__(kCandThreads) void k_pair_candidates(
     const uint32_t *__restrict__ bitmap, const uint2 *__restrict__ tab8, const int32_t *__restrict__ members2, int n_wl,
     const uint8_t *__restrict__ ext, int ext_stride, const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr,
@@ -843,7 +848,15 @@ __global__ __launch_bounds__(kCandThreads) void k_pair_candidates(
     const int n_list = *n_list_ptr;
     const int tid = threadIdx.x;
     if ((int)blockIdx.x * kCandThreads >= n_list) return;         // workgroup-uniform
-    for (int i = tid; i < kPairCount * kPairBmWords; i += kCandThreads) bm[i] = bitmap[i];
+    {                                                             // 48 KB of bitmaps, every 16-byte load in flight at once
+        constexpr int kVec = kPairCount * kPairBmWords / 4 / kCandThreads;
+        static_assert(kVec * 4 * kCandThreads == kPairCount * kPairBmWords, "bitmap size must divide");
+        uint4 v[kVec];
+#pragma unroll
+        for (int i = 0; i < kVec; ++i) v[i] = ((const uint4 *)bitmap)[i * kCandThreads + tid];
+#pragma unroll
+        for (int i = 0; i < kVec; ++i) ((uint4 *)bm)[i * kCandThreads + tid] = v[i];
+    }
     __syncthreads();
     const int slot = blockIdx.x * kCandThreads + tid;
     if ((slot & ~63) >= n_list) return;                           // whole wave idle
@@ -859,6 +872,27 @@ __global__ __launch_bounds__(kCandThreads) void k_pair_candidates(
     const uint32_t tlo_ = (uint32_t)tc, thi_ = (uint32_t)(tc >> 32);
     uint32_t cnt = 0;
     uint32_t *out = cand + slot;
+
+    // one bucket entry -> candidate slots (e.x = bucket size (saturating) | offset << 8, e.y = first member)
+    auto consume = [&](uint2 e, bool h, const int32_t *mp) {
+        const uint32_t n_mem = h ? (e.x & 0xFFu) : 0u;
+        if (n_mem) {
+            out[(size_t)min(cnt, (uint32_t)cap) * cand_stride] = e.y;          // row `cap` of the matrix is a dump row
+            ++cnt;
+            if (n_mem > 1u) {                                     // rare for small whitelists
+                if (n_mem == 0xFFu) cnt = 0x40000000u;            // saturated size: let the ordered scan do this row
+                else for (uint32_t k = 1; k < n_mem; ++k) {
+                    out[(size_t)min(cnt, (uint32_t)cap) * cand_stride] = (uint32_t)mp[(e.x >> 8) + k];
+                    ++cnt;
+                }
+            }
+        }
+    };
+    uint2 e_prev[kCandPop];
+    bool h_prev[kCandPop];
+#pragma unroll
+    for (int q = 0; q < kCandPop; ++q) { e_prev[q] = make_uint2(0u, 0u); h_prev[q] = false; }
+    const int32_t *mp_prev = members2;
 
     auto do_pair = [&](auto pa_c, auto pb_c, auto p_c) {
         constexpr int a = decltype(pa_c)::value, b = decltype(pb_c)::value, p = decltype(p_c)::value;
@@ -885,41 +919,41 @@ __global__ __launch_bounds__(kCandThreads) void k_pair_candidates(
         const uint2 *tp = tab8 + (size_t)p * 65536;
         const int32_t *mp = members2 + (size_t)p * n_wl;
         const uint64_t tcc = ((uint64_t)thi << 32) | tlo;
-        while (__builtin_amdgcn_ballot_w64((mlo | mhi) != 0) != 0) {
-            uint2 e[kPairPop];                                    // straight-line: all look-ups of the step in flight together
-            bool h[kPairPop];
+        auto pop = [&](bool &h) -> uint32_t {                     // next hit of this lane -> its 16-bit key
+            const bool lo = mlo != 0;
+            const uint32_t w = lo ? mlo : mhi;
+            h = w != 0;
+            const int pos = (int)__builtin_ctz(w | 0x80000000u) + (lo ? 0 : 32);
+            const uint32_t w2 = w & (w - 1u);
+            mlo = lo ? w2 : mlo;
+            mhi = lo ? mhi : w2;
+            const int xi = (pos * 13) >> 6, di = pos - 5 * xi;    // pos / 5, pos % 5 for pos < 64
+            const int ja = 4 * a - 2 + xi, jb = ja + 4 * (b - a) + di - 2;
+            return (((uint32_t)(tcc >> ((2 * ja) & 63)) & 0xFFu) << 8) | ((uint32_t)(tcc >> ((2 * jb) & 63)) & 0xFFu);
+        };
+        uint2 e[kCandPop];
+        bool h[kCandPop];
 #pragma unroll
-            for (int q = 0; q < kPairPop; ++q) {
-                const bool lo = mlo != 0;
-                const uint32_t w = lo ? mlo : mhi;
-                h[q] = w != 0;
-                const int pos = (int)__builtin_ctz(w | 0x80000000u) + (lo ? 0 : 32);
-                const uint32_t w2 = w & (w - 1u);
-                mlo = lo ? w2 : mlo;
-                mhi = lo ? mhi : w2;
-                const int xi = (pos * 13) >> 6, di = pos - 5 * xi;              // pos / 5, pos % 5 for pos < 64
-                const int ja = 4 * a - 2 + xi, jb = ja + 4 * (b - a) + di - 2;
-                const uint32_t key = (((uint32_t)(tcc >> ((2 * ja) & 63)) & 0xFFu) << 8) | ((uint32_t)(tcc >> ((2 * jb) & 63)) & 0xFFu);
-                e[q] = tp[h[q] ? key : 0u];
-            }
-#pragma unroll
-            for (int q = 0; q < kPairPop; ++q) {
-                const uint32_t n_mem = h[q] ? e[q].x : 0u;        // bucket size; e.y = the barcode (size 1) or the offset
-                if (n_mem == 1u) {
-                    if (cnt < (uint32_t)cap) out[(size_t)cnt * cand_stride] = e[q].y;
-                    ++cnt;
-                } else if (n_mem > 1u) {                          // rare for small whitelists
-                    for (uint32_t k = 0; k < n_mem; ++k) {
-                        if (cnt < (uint32_t)cap) out[(size_t)cnt * cand_stride] = (uint32_t)mp[e[q].y + k];
-                        ++cnt;
-                    }
-                }
-            }
+        for (int q = 0; q < kCandPop; ++q) {                      // issue this pair's look-ups ...
+            const uint32_t key = pop(h[q]);
+            e[q] = tp[h[q] ? key : 0u];
         }
+#pragma unroll
+        for (int q = 0; q < kCandPop; ++q) consume(e_prev[q], h_prev[q], mp_prev);   // ... then retire the previous pair's
+        while (__builtin_amdgcn_ballot_w64((mlo | mhi) != 0) != 0) {                 // rare: more than kCandPop hits in one pair
+            bool hh;
+            const uint32_t key = pop(hh);
+            consume(tp[hh ? key : 0u], hh, mp);
+        }
+#pragma unroll
+        for (int q = 0; q < kCandPop; ++q) { e_prev[q] = e[q]; h_prev[q] = h[q]; }
+        mp_prev = mp;
     };
 #define BZ_PAIR(A, B, P) do_pair(std::integral_constant<int, A>{}, std::integral_constant<int, B>{}, std::integral_constant<int, P>{})
     BZ_PAIR(0, 1, 0); BZ_PAIR(0, 2, 1); BZ_PAIR(0, 3, 2); BZ_PAIR(1, 2, 3); BZ_PAIR(1, 3, 4); BZ_PAIR(2, 3, 5);
 #undef BZ_PAIR
+#pragma unroll
+    for (int q = 0; q < kCandPop; ++q) consume(e_prev[q], h_prev[q], mp_prev);
     if (active) cand_cnt[slot] = cnt > (uint32_t)cap ? kCandOverflow : cnt;
 }
 
@@ -959,18 +993,25 @@ __global__ __launch_bounds__(256) void k_pair_verify(
     int nacc = 0;                                                 // distinct accepted barcode indices in events[][tid]
     const uint32_t *cp = cand + slot;
 
-    // candidates of round k: slots 2k and 2k+1 (an odd tail repeats the first); one round is prefetched
-    uint32_t i0 = 0, i1 = 0, p0 = 0, p1 = 0;
-    auto fetch = [&](uint32_t k, uint32_t &a0, uint32_t &a1, uint32_t &q0, uint32_t &q1) {
+    // candidates of round k: slots 2k and 2k+1 (an odd tail repeats the first).  Two-deep pipeline: the candidate
+    // indices of round k+2 and the bit planes of round k+1 are requested before round k's automaton runs, so no
+    // round waits on a load it issued itself.
+    auto load_idx = [&](uint32_t k, uint32_t &a0, uint32_t &a1) {     // unconditional loads (clamped slot): no wait, no branch
         const bool v0 = 2 * k < cnt, v1 = 2 * k + 1 < cnt;
-        a0 = v0 ? cp[(size_t)(2 * k) * cand_stride] : 0u;
-        a1 = v1 ? cp[(size_t)(2 * k + 1) * cand_stride] : a0;
-        q0 = planes32[a0]; q1 = planes32[a1];
+        const uint32_t x0 = cp[(size_t)(v0 ? 2 * k : 0u) * cand_stride];
+        const uint32_t x1 = cp[(size_t)(v1 ? 2 * k + 1 : 0u) * cand_stride];
+        a0 = v0 ? x0 : 0u;
+        a1 = v1 ? x1 : a0;
     };
-    fetch(0, i0, i1, p0, p1);
+    uint32_t i0, i1, n0, n1;
+    load_idx(0, i0, i1);
+    load_idx(1, n0, n1);
+    uint32_t p0 = planes32[i0], p1 = planes32[i1];
     for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(2 * k < cnt) != 0; ++k) {
         const uint32_t c0 = i0, c1 = i1, q0 = p0, q1 = p1;
-        fetch(k + 1, i0, i1, p0, p1);                             // next round's loads fly under this round's automaton
+        i0 = n0; i1 = n1;
+        p0 = planes32[i0]; p1 = planes32[i1];                     // round k+1's planes
+        load_idx(k + 2, n0, n1);                                  // round k+2's indices
         const uint32_t bh = (q0 & 0xFFFFu) | (q1 << 16), bl = (q0 >> 16) | (q1 & 0xFFFF0000u);
         PackedScan<K> A;
         A.init();

@@ -619,6 +619,19 @@ __global__ __launch_bounds__(256) void k_scan_seeded(
 // and there is no tail of half-empty workgroups.  Verify, events and the replay of the ordered fold are
 // the ones of k_scan_seeded.
 constexpr int kPairCount = 6;
+// Is the probe (pieces a < b, window ja = 4a - 2 + xi, jb = ja + 4(b - a) + di - 2) admissible?  With x = xi - 2 the
+// shift of piece a and delta = di - 2 the shift between the pieces, an alignment needs u >= max(0, -x) operations in
+// front of piece a (the match cannot start before column 0), v >= |delta| between the pieces (adjacent pieces: only
+// insertions, delta >= 0) and w >= x + delta - 4 behind piece b (the match must end inside <= 20 columns), and
+// u + v + w <= 2.  131 of the 6 x 9 x 5 combinations remain (162 with the window bounds alone).
+constexpr bool pair_probe_ok(int a, int b, int xi, int di) {
+    const int ja = 4 * a - 2 + xi, jb = ja + 4 * (b - a) + di - 2;
+    if (ja < 0 || ja + 4 > kTextCols || jb < 0 || jb + 4 > kTextCols) return false;
+    const int x = xi - 2, d = di - 2;
+    if (b == a + 1 && d < 0) return false;
+    const int u = x < 0 ? -x : 0, v = d < 0 ? -d : d, w = x + d - 4 > 0 ? x + d - 4 : 0;
+    return u + v + w <= 2;
+}
 constexpr int kPairBmWords = 2048;                                // 65536 bits per pair
 constexpr int kPairTab = 65537;
 constexpr int kPairQCap = 16;                                     // FIFO entries per lane
@@ -727,8 +740,7 @@ __global__ __launch_bounds__(kPairThreads) void k_scan_paired(
 #pragma unroll
                 for (int di = 0; di < 5; ++di) {
                     const int ja = 4 * a - 2 + xi, jb = ja + 4 * (b - a) + di - 2;
-                    const bool ok = ja >= 0 && ja + 4 <= kTextCols && jb >= 0 && jb + 4 <= kTextCols &&
-                                    !(b == a + 1 && di < 2);      // adjacent pieces: only insertions fit between them
+                    const bool ok = pair_probe_ok(a, b, xi, di);
                     if (ok) {
                         const uint32_t ca = 2 * ja + 8 <= 32 ? (tlo >> (2 * ja)) : 2 * ja >= 32 ? (thi >> ((2 * ja) & 31)) : __builtin_amdgcn_alignbit(thi, tlo, (2 * ja) & 31);
                         const uint32_t cb = 2 * jb + 8 <= 32 ? (tlo >> (2 * jb)) : 2 * jb >= 32 ? (thi >> ((2 * jb) & 31)) : __builtin_amdgcn_alignbit(thi, tlo, (2 * jb) & 31);
@@ -903,7 +915,7 @@ __global__ __launch_bounds__(kCandThreads) void k_pair_candidates(
 #pragma unroll
             for (int di = 0; di < 5; ++di) {
                 const int ja = 4 * a - 2 + xi, jb = ja + 4 * (b - a) + di - 2;
-                const bool ok = ja >= 0 && ja + 4 <= kTextCols && jb >= 0 && jb + 4 <= kTextCols && !(b == a + 1 && di < 2);
+                const bool ok = pair_probe_ok(a, b, xi, di);
                 if (ok) {
                     const uint32_t ca = 2 * ja + 8 <= 32 ? (tlo >> (2 * ja)) : 2 * ja >= 32 ? (thi >> ((2 * ja) & 31)) : __builtin_amdgcn_alignbit(thi, tlo, (2 * ja) & 31);
                     const uint32_t cb = 2 * jb + 8 <= 32 ? (tlo >> (2 * jb)) : 2 * jb >= 32 ? (thi >> ((2 * jb) & 31)) : __builtin_amdgcn_alignbit(thi, tlo, (2 * jb) & 31);

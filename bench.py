@@ -104,7 +104,7 @@ def attach_profile(roof, roof_brute):
     counters, which cannot be read inside this process: tools/profile.sh collects them with rocprofv3
     (separate --pmc passes of this very command) and the newest committed profiles/*_pmc.json is read
     back here.  gfx950 corrections per MI355X_MICROARCH.md 'HBM': FETCH_SIZE is doubled, WRITE_SIZE is
-    exact, both are KiB."""
+    exact, both are KiB.  A roofline object that spans several kernels sums them."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc.json")))
     if not files:
@@ -112,17 +112,26 @@ def attach_profile(roof, roof_brute):
     with open(files[-1]) as f:
         prof = json.load(f)
     for roof_obj, cls in ((roof, "product"), (roof_brute, "all_rows")):
-        ent = prof["kernels"].get("bz::" + roof_obj["kernel"], {}).get("classes", {})
-        c = ent.get(cls) or ent.get("all")
-        if not c:
+        traffic, insts, us, found = 0.0, 0.0, 0.0, 0
+        for kname in roof_obj["kernels"]:
+            ent = prof["kernels"].get("bz::" + kname, {}).get("classes", {})
+            c = ent.get(cls) or ent.get("all")
+            if not c or "avg_us" not in c:
+                continue
+            found += 1
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                traffic += (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+            insts += c.get("SQ_INSTS_VALU", 0.0)
+            us += c["avg_us"]
+        if found != len(roof_obj["kernels"]):
             continue
         roof_obj["profile"] = os.path.relpath(files[-1], ROOT)
-        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            roof_obj["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-        if "SQ_INSTS_VALU" in c and "avg_us" in c:
-            lane_ops = c["SQ_INSTS_VALU"] * 64.0 / (c["avg_us"] * 1e-6) / 1e12
+        if traffic:
+            roof_obj["traffic"] = traffic
+        if insts and us:
+            lane_ops = insts * 64.0 / (us * 1e-6) / 1e12
             roof_obj["issued"] = {"valu_lane_Tops": lane_ops, "frac_of_peak": lane_ops / PEAK_INT32_TOPS,
-                                  "valu_instructions_per_launch": c["SQ_INSTS_VALU"], "launch_us_in_profile": c["avg_us"]}
+                                  "valu_instructions_per_launch": insts, "launch_us_in_profile": us}
 
 
 def main():
@@ -228,33 +237,44 @@ def main():
         plumb.barrier()
         return
 
-    def roofline(kernel, t, note):
+    def roofline(kernels, ms, t, note):
         pairs = t["rows_bitparallel"] * a.cells
-        sec = t["scan_ms"] * 1e-3
+        sec = ms * 1e-3
         ach = pairs * ALG_OPS_PER_PAIR / sec / 1e12
         return {"bound": "valu-int32", "achieved": ach, "peak": PEAK_INT32_TOPS, "unit": "Top/s",
-                "frac": ach / PEAK_INT32_TOPS, "traffic": None, "kernel": kernel, "launch_ms": t["scan_ms"],
-                "algorithmic_ops_per_pair": ALG_OPS_PER_PAIR, "pairs_per_launch": pairs,
+                "frac": ach / PEAK_INT32_TOPS, "traffic": None, "kernel": " + ".join(kernels), "kernels": kernels,
+                "launch_ms": ms, "algorithmic_ops_per_pair": ALG_OPS_PER_PAIR, "pairs_per_launch": pairs,
                 "rows_scored_per_launch": t["rows_bitparallel"], "pairs_per_s": pairs / sec, "note": note}
 
     row_bytes = ext.shape[1] + 3 + 7
-    roof = roofline(f"k_scan_seeded<{a.max_ed}>", t_short,
-                    "dominant kernel of the timed region.  `achieved` prices every (row, barcode) pair the kernel DECIDES at "
-                    "SURVEY 8d's 340 ops; the kernel proves ~98 % of them cannot match (pigeonhole seeds) without running "
-                    "the automaton, so frac > 1 is algorithmic gain, not an issue rate: the executed-instruction rate is "
-                    "`issued` (rocprof SQ_INSTS_VALU), and the all-pairs kernel is priced in roofline_bruteforce")
-    roof_brute = roofline(f"k_scan_bitparallel<{a.max_ed}>", t_all_brute,
+    if a.max_ed == 2 and t_short["candidates_ms"] > 0:
+        scan_kernels, scan_ms = ["k_pair_candidates", f"k_pair_verify<{a.max_ed}>"], t_short["candidates_ms"] + t_short["verify_ms"]
+    else:
+        scan_kernels, scan_ms = [f"k_scan_seeded<{a.max_ed}>"], t_short["scan_ms"]
+    roof = roofline(scan_kernels, scan_ms, t_short,
+                    "dominant kernels of the timed region (the scan = candidate generation + verify).  `achieved` prices every "
+                    "(row, barcode) pair the scan DECIDES at SURVEY 8d's 340 ops; the pair seeds prove ~99.8 % of them cannot "
+                    "match without running the automaton, so frac > 1 is algorithmic gain, not an issue rate: the "
+                    "executed-instruction rate is `issued` (rocprof SQ_INSTS_VALU), the all-pairs kernel is priced in "
+                    "roofline_bruteforce and the whole step against HBM in roofline_hbm")
+    roof_brute = roofline([f"k_scan_bitparallel<{a.max_ed}>"], t_all_brute["scan_ms"], t_all_brute,
                           "all-pairs leg (BZ_OPT_SCAN_MODE 1, shortcut off): every pair runs the packed automaton, "
                           "124.5 VALU instructions per pair against SURVEY 8d's 340-op Myers count")
-    roof["hbm_algorithmic_GBps"] = (t_short["rows"] * row_bytes + a.cells * 20) / (t_short["total_ms"] * 1e-3) / 1e9
     roof["measured_valu_ceiling_Tops"] = roof_brute["measured_valu_ceiling_Tops"] = probe_ops / 1e12
     attach_profile(roof, roof_brute)
+    step_bytes = a.rows * row_bytes + a.cells * 20
+    roof_hbm = {"bound": "hbm", "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                "kernel": "whole step (classify + scan + histogram)", "algorithmic_bytes_per_row": row_bytes,
+                "note": "algorithmic HBM bytes of one step (rows in + results out + the whitelist once) over the timed step: the "
+                        "step is nowhere near the HBM roof; at 1M rows (293K scored = 4.5 waves per SIMD) it is bound by the "
+                        "latency of dependent gathers and by VALU issue in the verify kernel"}
 
     out = {
         "metric": "reads assigned/sec (whole node) vs 5k-cell whitelist; % int roofline",
         "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u32 bit-vectors (2 x 16-bit automata per lane register)", "data": "synthetic",
+        "dtype": "u32", "dtype_note": "32-bit integer bit-vectors: two 16-bit automata per lane register", "data": "synthetic",
         "config": {"workload": f"configs[1]: synthetic 10x 3v3, {a.rows} nanopore-error reads per GPU vs "
                                f"{a.cells}-cell whitelist, max_ed {a.max_ed}, exact-match shortcut on",
                    "rows_per_gpu": a.rows, "cells": a.cells, "umi_len": 12, "errors": rows["params"],
@@ -263,13 +283,14 @@ def main():
         "assigned": assigned_total, "rows_counted": rows_total,
         "rows_scored_per_step": t_short["rows_bitparallel"], "rows_generic_per_step": t_short["rows_generic"],
         "rows_redone_per_step": t_short["rows_redo"],
-        "kernel_ms": {k: t_short[k] for k in ("total_ms", "classify_ms", "scan_ms", "generic_ms", "hist_ms")},
+        "kernel_ms": {k: t_short[k] for k in ("total_ms", "classify_ms", "scan_ms", "candidates_ms", "verify_ms", "generic_ms", "hist_ms")},
+        "kernel_ms_note": "HIP events on the slot's stream in separate profiled launches (BZ_OPT_PROFILE): each event adds ~6 us of idle GPU, so total_ms > ms_per_step",
         "all_rows_scored": {"seeded": {"reads_per_s": t_all_seeded["rows"] / (t_all_seeded["total_ms"] * 1e-3),
                                        "scan_ms": t_all_seeded["scan_ms"], "rows_scored": t_all_seeded["rows_bitparallel"]},
                             "bruteforce": {"reads_per_s": t_all_brute["rows"] / (t_all_brute["total_ms"] * 1e-3),
                                            "scan_ms": t_all_brute["scan_ms"], "rows_scored": t_all_brute["rows_bitparallel"]}},
         "pcie_inclusive_reads_per_s": pcie_rate,
-        "roofline": roof, "roofline_bruteforce": roof_brute,
+        "roofline": roof, "roofline_bruteforce": roof_brute, "roofline_hbm": roof_hbm,
     }
     if not a.no_cpu_baseline and world == 1:
         eng.run(0, a.max_ed)                       # shortcut on again: the rows the oracle sample is checked against

@@ -75,7 +75,8 @@ constexpr int kNcclSum = 0, kNcclMax = 2, kNcclInt64 = 4, kNcclFloat64 = 8;   //
 
 struct Slot {
     hipStream_t stream = nullptr;
-    hipEvent_t ev[5] = {};
+    hipEvent_t ev[7] = {};      // 0..4 run phases; 5, 6 = after k_pair_candidates / after k_pair_verify
+    bool timed_pair = false;
     int64_t cap = 0;          // rows
     int cap_stride = 0;
     int64_t n = 0;
@@ -118,6 +119,7 @@ struct bz_engine {
     int n_cu = 0;
     int bucket_bits = 0, n_blk = 0;
     uint32_t *d_sorted_codes = nullptr;
+    uint2 *d_sorted_pairs = nullptr;      // {code, original index} sorted by code (k_classify_packed)
     int32_t *d_sorted_idx = nullptr;
     uint8_t *d_wl_bytes = nullptr;
     int64_t *d_wl_off = nullptr;
@@ -143,7 +145,8 @@ int use(bz_handle h) {
 }
 
 void free_whitelist(bz_handle h) {
-    hipFree(h->d_planes); hipFree(h->d_sorted_codes); hipFree(h->d_sorted_idx);
+    hipFree(h->d_planes); hipFree(h->d_sorted_codes); hipFree(h->d_sorted_idx); hipFree(h->d_sorted_pairs);
+    h->d_sorted_pairs = nullptr;
     hipFree(h->d_wl_bytes); hipFree(h->d_wl_off); hipFree(h->d_counts); hipFree(h->d_hist_partial);
     h->d_hist_partial = nullptr;
     hipFree(h->d_grams); hipFree(h->d_planes32); hipFree(h->d_bucket);
@@ -245,11 +248,13 @@ int launch_pair_two_kernels(bz_handle h, Slot &s) {
     hipLaunchKernelGGL(bz::k_pair_candidates, dim3(ga), dim3(bz::kCandThreads), 0, s.stream, h->d_pair_bitmap, h->d_pair_tab8,
                        h->d_pair_members, (int)h->n_wl, s.d_ext, s.stride, s.d_fast, s.d_counters, s.d_cand, stride, h->pair_cap,
                        s.d_cand_cnt);
+    if (h->profile) HIP_TRY(hipEventRecord(s.ev[5], s.stream));
     const int block = 256;
     const int grid = (int)((s.n + block - 1) / block);
     hipLaunchKernelGGL(bz::k_pair_verify<2>, dim3(grid), dim3(block), 0, s.stream, s.d_cand, stride, s.d_cand_cnt, h->d_planes32,
                        s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_redo, s.d_counters + 2, s.d_hit, s.d_ed,
                        s.d_end, s.d_flags);
+    if (h->profile) { HIP_TRY(hipEventRecord(s.ev[6], s.stream)); s.timed_pair = true; }
     hipLaunchKernelGGL(bz::k_scan_filtered<2>, dim3(grid), dim3(block), 0, s.stream, (const uint4 *)h->d_grams, h->d_planes32, h->n_blk,
                        (int)h->n_wl, s.d_ext, s.stride, s.d_len, s.d_redo, s.d_counters + 2, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
     return BZ_OK;
@@ -427,6 +432,12 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
         HIP_TRY(hipMemcpy(h->d_planes, planes.data(), n_pairs * sizeof(uint2), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->d_sorted_codes, sorted.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->d_sorted_idx, idx.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+        {
+            std::vector<uint2> pairs(n);
+            for (int64_t k = 0; k < n; ++k) pairs[k] = make_uint2(sorted[k], (uint32_t)idx[k]);
+            HIP_TRY(hipMalloc(&h->d_sorted_pairs, n * sizeof(uint2)));
+            HIP_TRY(hipMemcpy(h->d_sorted_pairs, pairs.data(), n * sizeof(uint2), hipMemcpyHostToDevice));
+        }
         h->n_pairs = (int)n_pairs;
 
         // bucket table for the shortcut look-up: ~4 buckets per barcode, 2^8 .. 2^24 buckets
@@ -581,11 +592,18 @@ int bz_assign_run(bz_handle h, int slot, int max_ed) {
     // HIP events between the kernels cost ~6 us of idle GPU each: recorded only when BZ_OPT_PROFILE is on
     const bool prof = h->profile != 0;
     s.timed = prof;
+    s.timed_pair = false;
     if (n == 0) { memset(s.h_counters, 0, 4 * sizeof(int32_t)); s.timed = false; s.ran = true; return BZ_OK; }
     int32_t *const next_counters = s.d_counters_base + (s.d_counters == s.d_counters_base ? 4 : 0);
     if (prof) HIP_TRY(hipEventRecord(s.ev[0], s.stream));
     if (n) {
-        hipLaunchKernelGGL(bz::k_classify, dim3((n + 256 * bz::kClassifyRows - 1) / (256 * bz::kClassifyRows)), dim3(256), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
+        const dim3 cgrid((n + bz::kClassifyThreads * bz::kClassifyRows - 1) / (bz::kClassifyThreads * bz::kClassifyRows));
+        if ((s.stride & 15) == 0 && s.stride >= 32)
+            hipLaunchKernelGGL(bz::k_classify_packed, cgrid, dim3(bz::kClassifyThreads), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
+                               s.d_bcl, n, h->wl_regular, h->d_sorted_pairs, (int)h->n_wl, h->d_bucket, h->bucket_bits, h->shortcut,
+                               h->force_generic, max_ed, s.d_fast, s.d_gen, s.d_counters, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+        else
+            hipLaunchKernelGGL(bz::k_classify, dim3((n + bz::kClassifyThreads * bz::kClassifyRows - 1) / (bz::kClassifyThreads * bz::kClassifyRows)), dim3(bz::kClassifyThreads), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
                            s.d_bcl, n, h->wl_regular, h->d_sorted_codes, h->d_sorted_idx, (int)h->n_wl, h->d_bucket, h->bucket_bits, h->shortcut,
                            h->force_generic, max_ed, s.d_fast, s.d_gen, s.d_counters, s.d_hit, s.d_ed, s.d_end, s.d_flags);
         HIP_TRY(hipGetLastError());
@@ -699,6 +717,10 @@ int bz_slot_timing(bz_handle h, int slot, float ms[8], int64_t counts[8]) {
         if (s.timed) {                                  // BZ_OPT_PROFILE was on for that run
             HIP_TRY(hipEventElapsedTime(&ms[0], s.ev[0], s.ev[4]));
             for (int i = 1; i <= 4; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], s.ev[i - 1], s.ev[i]));
+            if (s.timed_pair) {
+                HIP_TRY(hipEventElapsedTime(&ms[5], s.ev[1], s.ev[5]));
+                HIP_TRY(hipEventElapsedTime(&ms[6], s.ev[5], s.ev[6]));
+            }
         }
     }
     if (counts) {

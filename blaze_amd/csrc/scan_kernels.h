@@ -1206,9 +1206,118 @@ __global__ void k_pair(const uint8_t *a, int la, const uint8_t *b, int lb, int m
 // over the code's top `bucket_bits` bits gives the (short) range, a lower-bound search inside it the
 // entry (duplicates -> first index in caller order).  2-3 dependent loads instead of log2(n_wl).
 constexpr int kTotStripes = 64;
-constexpr int kClassifyRows = 4;                              // rows per thread: 1024 per workgroup, ONE list atomic pair per workgroup
+constexpr int kClassifyRows = 4;                              // rows per thread
+constexpr int kClassifyThreads = 1024;                        // 4096 rows per workgroup and ONE returned list atomic pair for them:
+                                                              // same-address returned atomics serialise at ~13 ns each, and 977
+                                                              // workgroups x 2 of them were most of this kernel's 32 us per 1M rows
+constexpr int kClassifyWaves = kClassifyThreads / 64;
 
-__global__ __launch_bounds__(256) void k_classify(
+// Staged form for the packed row layout: the four rows of a thread go through every step together (row bytes ->
+// bucket bounds -> search -> (code, index) pair -> stores), so a thread waits ~6 memory latencies instead of ~24.
+// The first form ran the rows one after another through divergent branches: 32 us per 1M rows with every wave
+// resident and nothing saturated.  sorted_pairs[i] = {code, original index}, sorted by code (stable).
+__global__ __launch_bounds__(kClassifyThreads) void k_classify_packed(
+    const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
+    const uint8_t *__restrict__ bc_off, const uint8_t *__restrict__ bc_len, int n, int wl_regular,
+    const uint2 *__restrict__ sorted_pairs, int n_wl, const int32_t *__restrict__ bucket_start, int bucket_bits,
+    int shortcut, int force_generic, int max_ed, int32_t *__restrict__ fast_list,
+    int32_t *__restrict__ gen_list, int32_t *__restrict__ counters, int32_t *__restrict__ hit_out,
+    int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
+    __shared__ int s_cnt[2][kClassifyRows][kClassifyWaves];   // [list][k][wave] -> exclusive offsets
+    __shared__ int s_base[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int r[kClassifyRows], len[kClassifyRows], off[kClassifyRows], bl[kClassifyRows];
+    bool in[kClassifyRows];
+#pragma unroll
+    for (int k = 0; k < kClassifyRows; ++k) {
+        r[k] = (blockIdx.x * kClassifyRows + k) * kClassifyThreads + threadIdx.x;
+        in[k] = r[k] < n;
+        const int rr = in[k] ? r[k] : 0;
+        len[k] = ext_len[rr]; off[k] = bc_off[rr]; bl[k] = bc_len[rr];
+    }
+    RowBytes rb[kClassifyRows];
+#pragma unroll
+    for (int k = 0; k < kClassifyRows; ++k) rb[k] = load_row_packed(ext + (size_t)(in[k] ? r[k] : 0) * ext_stride);
+    const bool search = wl_regular && shortcut;               // wave-uniform
+    bool regular[kClassifyRows];
+    uint32_t code[kClassifyRows];
+    int lo[kClassifyRows], hi[kClassifyRows];
+#pragma unroll
+    for (int k = 0; k < kClassifyRows; ++k) {
+        if (!in[k]) bl[k] = 0;
+        bool ok = wl_regular && !force_generic && bl[k] == kBcLen && len[k] >= kBcLen && len[k] <= kTextCols && max_ed <= kMaxK;
+        uint32_t c16 = 0;
+#pragma unroll
+        for (int j = 0; j < kTextCols; ++j) {
+            const uint32_t c = rb[k].at(j);
+            ok = ok && (j >= len[k] || is_acgt(c));
+            const int i = j - off[k];
+            if (i >= 0 && i < kBcLen && j < len[k]) c16 |= base_code(c) << (2 * i);
+        }
+        regular[k] = ok; code[k] = c16;
+        lo[k] = 0; hi[k] = 0;
+    }
+    uint2 pr[kClassifyRows];
+    if (search) {
+#pragma unroll
+        for (int k = 0; k < kClassifyRows; ++k) {
+            const uint32_t b = (regular[k] && bucket_bits) ? code[k] >> (32 - bucket_bits) : 0u;
+            const int l = bucket_start[b], h = bucket_start[b + 1];
+            lo[k] = regular[k] ? l : 0; hi[k] = regular[k] ? h : 0;
+        }
+        for (;;) {                                            // lower bound inside the (tiny) buckets, four rows per step
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < kClassifyRows; ++k) any = any || lo[k] < hi[k];
+            if (__builtin_amdgcn_ballot_w64(any) == 0) break;
+            uint32_t v[kClassifyRows];
+#pragma unroll
+            for (int k = 0; k < kClassifyRows; ++k) v[k] = sorted_pairs[lo[k] < hi[k] ? (lo[k] + hi[k]) >> 1 : 0].x;
+#pragma unroll
+            for (int k = 0; k < kClassifyRows; ++k) {
+                const int mid = (lo[k] + hi[k]) >> 1;
+                if (lo[k] < hi[k]) { if (v[k] < code[k]) lo[k] = mid + 1; else hi[k] = mid; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kClassifyRows; ++k) pr[k] = sorted_pairs[min(lo[k], n_wl - 1)];
+    }
+    int route[kClassifyRows], pos[kClassifyRows];
+#pragma unroll
+    for (int k = 0; k < kClassifyRows; ++k) {
+        int hit = -1, rt = 0;
+        uint32_t flags = 0;
+        int ed = min(max_ed, 127);
+        if (bl[k] == 0) flags = kFlagBlank;
+        else if (!regular[k]) rt = 2;
+        else {
+            rt = 1;
+            if (search && lo[k] < n_wl && pr[k].x == code[k]) { hit = (int)pr[k].y; ed = 0; flags = kFlagExact; rt = 0; }
+        }
+        if (in[k]) { hit_out[r[k]] = hit; ed_out[r[k]] = (int8_t)ed; end_out[r[k]] = -1; flags_out[r[k]] = (uint8_t)flags; }
+        const unsigned long long m1 = __builtin_amdgcn_ballot_w64(rt == 1), m2 = __builtin_amdgcn_ballot_w64(rt == 2);
+        route[k] = rt;
+        pos[k] = rt == 1 ? __popcll(m1 & below) : __popcll(m2 & below);
+        if (lane == 0) { s_cnt[0][k][wave] = __popcll(m1); s_cnt[1][k][wave] = __popcll(m2); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {                                    // one thread per list: exclusive scan of 64 counts, one atomic
+        int *c = &s_cnt[threadIdx.x][0][0];
+        int tot = 0;
+        for (int i = 0; i < kClassifyRows * kClassifyWaves; ++i) { const int v = c[i]; c[i] = tot; tot += v; }
+        s_base[threadIdx.x] = tot ? atomicAdd(&counters[threadIdx.x], tot) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kClassifyRows; ++k) {
+        if (route[k] == 1) fast_list[s_base[0] + s_cnt[0][k][wave] + pos[k]] = r[k];
+        else if (route[k] == 2) gen_list[s_base[1] + s_cnt[1][k][wave] + pos[k]] = r[k];
+    }
+}
+
+// General form (any row stride).
+__global__ __launch_bounds__(kClassifyThreads) void k_classify(
     const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
     const uint8_t *__restrict__ bc_off, const uint8_t *__restrict__ bc_len, int n, int wl_regular,
     const uint32_t *__restrict__ sorted_codes, const int32_t *__restrict__ sorted_idx, int n_wl,
@@ -1216,7 +1325,7 @@ __global__ __launch_bounds__(256) void k_classify(
     int shortcut, int force_generic, int max_ed, int32_t *__restrict__ fast_list,
     int32_t *__restrict__ gen_list, int32_t *__restrict__ counters, int32_t *__restrict__ hit_out,
     int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
-    __shared__ int s_cnt[2][kClassifyRows][4];                // [list][k][wave] -> exclusive offsets
+    __shared__ int s_cnt[2][kClassifyRows][kClassifyWaves];                // [list][k][wave] -> exclusive offsets
     __shared__ int s_base[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -1224,7 +1333,7 @@ __global__ __launch_bounds__(256) void k_classify(
     int pos[kClassifyRows];                                   // rank inside (wave, k)
 #pragma unroll
     for (int k = 0; k < kClassifyRows; ++k) {
-        const int r = (blockIdx.x * kClassifyRows + k) * 256 + threadIdx.x;
+        const int r = (blockIdx.x * kClassifyRows + k) * kClassifyThreads + threadIdx.x;
         const bool in = r < n;
         const int len = in ? ext_len[r] : 0, off = in ? bc_off[r] : 0, bl = in ? bc_len[r] : 0;
         int hit = -1;
@@ -1266,16 +1375,16 @@ __global__ __launch_bounds__(256) void k_classify(
         if (lane == 0) { s_cnt[0][k][wave] = __popcll(m1); s_cnt[1][k][wave] = __popcll(m2); }
     }
     __syncthreads();
-    if (threadIdx.x < 2) {                                    // one thread per list: exclusive scan of 16 counts, one atomic
+    if (threadIdx.x < 2) {                                    // one thread per list: exclusive scan of 64 counts, one atomic
         int *c = &s_cnt[threadIdx.x][0][0];
         int tot = 0;
-        for (int i = 0; i < kClassifyRows * 4; ++i) { const int v = c[i]; c[i] = tot; tot += v; }
+        for (int i = 0; i < kClassifyRows * kClassifyWaves; ++i) { const int v = c[i]; c[i] = tot; tot += v; }
         s_base[threadIdx.x] = tot ? atomicAdd(&counters[threadIdx.x], tot) : 0;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kClassifyRows; ++k) {
-        const int r = (blockIdx.x * kClassifyRows + k) * 256 + threadIdx.x;
+        const int r = (blockIdx.x * kClassifyRows + k) * kClassifyThreads + threadIdx.x;
         if (route[k] == 1) fast_list[s_base[0] + s_cnt[0][k][wave] + pos[k]] = r;
         else if (route[k] == 2) gen_list[s_base[1] + s_cnt[1][k][wave] + pos[k]] = r;
     }

@@ -112,7 +112,8 @@ int bz_assign_run(bz_handle h, int slot, int max_ed);
 int bz_assign_fetch(bz_handle h, int slot, int32_t *hit, int8_t *ed, int8_t *end_idx, uint8_t *flags);
 int bz_slot_sync(bz_handle h, int slot);
 /* HIP-event durations (ms) of the slot's last run (zeros unless BZ_OPT_PROFILE was on): ms[0] whole run, [1] classify+shortcut,
- * [2] bit-parallel scan, [3] generic scan, [4] histogram; counts[0] rows, [1] rows scored by the
+ * [2] bit-parallel scan, [3] generic scan, [4] histogram, [5] k_pair_candidates and [6] k_pair_verify inside [2] (zero when
+ * another scan ran); counts[0] rows, [1] rows scored by the
  * bit-parallel kernels, [2] rows scored by the generic kernel, [3] whitelist size, [4] rows the seeded
  * scan handed to the filtered scan (more than 8 near matches). */
 int bz_slot_timing(bz_handle h, int slot, float ms[8], int64_t counts[8]);

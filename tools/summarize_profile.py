@@ -68,7 +68,7 @@ for k in sorted(pmc):
     # classes by position: the same command runs in every pass, so dispatch i of each pass is the same launch
     d = durs.get(k, [])
     classes = {"all": list(range(n_disp))}
-    if "scan" in k and len(d) == n_disp and n_disp >= 4:
+    if ("scan" in k or "k_pair" in k) and len(d) == n_disp and n_disp >= 4:
         big = max(d)
         classes = {"product": [i for i in range(n_disp) if d[i] < 0.6 * big],
                    "all_rows": [i for i in range(n_disp) if d[i] >= 0.6 * big]}

@@ -294,3 +294,27 @@ def test_barcode_anywhere_in_the_text(engine, oracle, scan_mode):
         for tie in (0, 1):
             hit, ed, *_ = _compare(engine, oracle, ext, el, bo, bl, wl, max_ed, tie=tie, shortcut=False, scan_mode=scan_mode)
     assert (hit >= 0).sum() > n // 2
+
+
+def test_full_10x_whitelist_stress(engine, oracle):
+    """BASELINE configs[3] shape: rows against the full-size 10x list stand-in (6,794,880 distinct 16-mers).
+    The oracle would need hours, so the bar here is agreement of three independent device paths on every row
+    (pair-seeded one-kernel form, ordered 3-gram-filtered scan, brute force -- each oracle-checked at small sizes above)."""
+    full = synth.full_whitelist_codes(synth.FULL_WHITELIST_SIZE, seed=1)
+    assert full.size == synth.FULL_WHITELIST_SIZE
+    cells = synth.cell_whitelist_codes(5000, full, seed=2)
+    rows = synth.make_rows(6000, cells, full, sub=0.02, ins=0.01, dele=0.01, seed=5)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    engine.set_whitelist_codes16(synth.codes_to_bytes(full))
+    outs = {}
+    for mode in (0, 2, 1):
+        engine.set_option(_lib.BZ_OPT_SCAN_MODE, mode)
+        outs[mode] = engine.assign(ext, el, bo, bl, 2)
+    engine.set_option(_lib.BZ_OPT_SCAN_MODE, 0)
+    for mode in (2, 1):
+        for x, y in zip(outs[0], outs[mode]):
+            assert np.array_equal(x, y), f"mode 0 vs mode {mode}"
+    hit, ed, end, flags = outs[0]
+    assert (hit >= 0).sum() > 2000
+    # with 6.8M barcodes many rows have several near matches: ambiguity must show up
+    assert ((flags & _lib.BZ_F_AMBIG) != 0).sum() > 0

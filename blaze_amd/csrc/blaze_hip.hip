@@ -111,11 +111,11 @@ struct bz_engine {
     int32_t *d_bucket = nullptr;       // bucket table over the sorted codes' top bits
     int32_t *d_seed_tab[2] = {nullptr, nullptr};      // seed index, plan 0: pieces 5|5|6 (max_ed 2), plan 1: 8|8 (max_ed <= 1)
     int32_t *d_seed_members[2] = {nullptr, nullptr};  // per piece n_wl barcode indices grouped by the piece's code
-    uint32_t *d_pair_bitmap = nullptr;  // pair-seed index (k_scan_paired): 6 x 65536-bit bucket occupancy
+    uint32_t *d_pair_bitmap = nullptr;  // pair-seed index: 6 x 65536-bit bucket occupancy (k_pair_candidates)
     int32_t *d_pair_tab = nullptr;      //   6 CSR tables over the 16-bit key (piece a code << 8 | piece b code)
-    int32_t *d_pair_members = nullptr;  //   6 x n_wl barcode indices grouped by key, index order inside a bucket
+    uint2 *d_pair_members = nullptr;    //   6 x n_wl {barcode index, planes32} grouped by key, index order inside a bucket
     uint2 *d_pair_tab8 = nullptr;       //   6 x 65536 {bucket size, the barcode (size 1) or offset into members} (k_pair_candidates)
-    int pair_cap = 0;                   //   candidate slots per row for the two-kernel form, 0 = use k_scan_paired
+    int pair_cap = 0;                   //   candidate slots per row for the two-kernel form, 0 = use k_pair_stream
     int n_cu = 0;
     int bucket_bits = 0, n_blk = 0;
     uint32_t *d_sorted_codes = nullptr;
@@ -260,16 +260,14 @@ int launch_pair_two_kernels(bz_handle h, Slot &s) {
     return BZ_OK;
 }
 
-// pair-seeded scan (max_ed 2): persistent workgroups, one per CU; hand-over rows as above
-void launch_scan_paired(bz_handle h, Slot &s) {
-    const int chunks = (int)((s.n + 63) / 64), per_block = bz::kPairThreads / 64;
-    const int grid = std::max(1, std::min(h->n_cu, (chunks + per_block - 1) / per_block));
-    hipLaunchKernelGGL(bz::k_scan_paired<2>, dim3(grid), dim3(bz::kPairThreads), 0, s.stream, h->d_pair_bitmap, h->d_pair_tab,
-                       h->d_pair_members, h->d_planes32, (int)h->n_wl, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters,
-                       h->tie_rule, s.d_redo, s.d_counters + 2, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+// pair-seeded scan straight out of the buckets (any whitelist size); hand-over rows as above
+void launch_pair_stream(bz_handle h, Slot &s) {
     const int block = 256;
-    const int fgrid = (int)((s.n + block - 1) / block);
-    hipLaunchKernelGGL(bz::k_scan_filtered<2>, dim3(fgrid), dim3(block), 0, s.stream, (const uint4 *)h->d_grams, h->d_planes32, h->n_blk,
+    const int grid = (int)((s.n + block - 1) / block);
+    hipLaunchKernelGGL(bz::k_pair_stream<2>, dim3(grid), dim3(block), 0, s.stream, h->d_pair_tab, h->d_pair_members, h->d_planes32,
+                       (int)h->n_wl, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_redo, s.d_counters + 2,
+                       s.d_hit, s.d_ed, s.d_end, s.d_flags);
+    hipLaunchKernelGGL(bz::k_scan_filtered<2>, dim3(grid), dim3(block), 0, s.stream, (const uint4 *)h->d_grams, h->d_planes32, h->n_blk,
                        (int)h->n_wl, s.d_ext, s.stride, s.d_len, s.d_redo, s.d_counters + 2, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
 }
 
@@ -502,12 +500,13 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
             HIP_TRY(hipMemcpy(h->d_seed_members[pl], mem.data(), mem.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         }
 
-        // pair-seed index (k_scan_paired, max_ed 2): the barcode is cut into four 4-nt pieces; per pair of pieces a
+        // pair-seed index (max_ed 2): the barcode is cut into four 4-nt pieces; per pair of pieces a
         // CSR table over the 16-bit key + an occupancy bitmap the kernel keeps in LDS
         {
             const int pa[bz::kPairCount] = {0, 0, 0, 1, 1, 2}, pb[bz::kPairCount] = {1, 2, 3, 2, 3, 3};
             std::vector<uint32_t> bitmap((size_t)bz::kPairCount * bz::kPairBmWords, 0u);
-            std::vector<int32_t> tab((size_t)bz::kPairCount * bz::kPairTab), mem((size_t)bz::kPairCount * n);
+            std::vector<int32_t> tab((size_t)bz::kPairCount * bz::kPairTab);
+            std::vector<uint2> mem((size_t)bz::kPairCount * n);
             for (int p = 0; p < bz::kPairCount; ++p) {
                 auto key = [&](int64_t k) { return (((codes[k] >> (8 * pa[p])) & 0xFFu) << 8) | ((codes[k] >> (8 * pb[p])) & 0xFFu); };
                 int32_t *t = tab.data() + (size_t)p * bz::kPairTab;
@@ -519,15 +518,15 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
                 }
                 for (int b = 0; b < bz::kPairTab - 1; ++b) t[b + 1] += t[b];
                 std::vector<int32_t> fill(t, t + bz::kPairTab - 1);
-                int32_t *m = mem.data() + (size_t)p * n;
-                for (int64_t k = 0; k < n; ++k) m[fill[key(k)]++] = (int32_t)k;
+                uint2 *m = mem.data() + (size_t)p * n;
+                for (int64_t k = 0; k < n; ++k) m[fill[key(k)]++] = make_uint2((uint32_t)k, planes32[k]);
             }
             HIP_TRY(hipMalloc(&h->d_pair_bitmap, bitmap.size() * sizeof(uint32_t)));
             HIP_TRY(hipMalloc(&h->d_pair_tab, tab.size() * sizeof(int32_t)));
-            HIP_TRY(hipMalloc(&h->d_pair_members, mem.size() * sizeof(int32_t)));
+            HIP_TRY(hipMalloc(&h->d_pair_members, mem.size() * sizeof(uint2)));
             HIP_TRY(hipMemcpy(h->d_pair_bitmap, bitmap.data(), bitmap.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(h->d_pair_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(h->d_pair_members, mem.data(), mem.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(h->d_pair_members, mem.data(), mem.size() * sizeof(uint2), hipMemcpyHostToDevice));
             // two-kernel form: 8-byte table entries and a per-row candidate capacity of twice the expected number of
             // chance candidates (162 probes x bucket occupancy) plus room for the true ones
             const double chance = 162.0 * (double)n / 65536.0;
@@ -536,10 +535,10 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
                 std::vector<uint2> tab8((size_t)bz::kPairCount * 65536);
                 for (int p = 0; p < bz::kPairCount; ++p) {
                     const int32_t *t = tab.data() + (size_t)p * bz::kPairTab;
-                    const int32_t *m = mem.data() + (size_t)p * n;
+                    const uint2 *m = mem.data() + (size_t)p * n;
                     for (int b = 0; b < 65536; ++b) {
                         const uint32_t c = (uint32_t)(t[b + 1] - t[b]);       // {size (saturating) | offset << 8, first member}
-                        tab8[(size_t)p * 65536 + b] = make_uint2(std::min(c, 255u) | ((uint32_t)t[b] << 8), c ? (uint32_t)m[t[b]] : 0u);
+                        tab8[(size_t)p * 65536 + b] = make_uint2(std::min(c, 255u) | ((uint32_t)t[b] << 8), c ? m[t[b]].x : 0u);
                     }
                 }
                 HIP_TRY(hipMalloc(&h->d_pair_tab8, tab8.size() * sizeof(uint2)));
@@ -621,7 +620,7 @@ int bz_assign_run(bz_handle h, int slot, int max_ed) {
             case 1: if (seeded) launch_scan_seeded<1>(h, s); else if (filtered) launch_scan_filtered<1>(h, s); else launch_scan<1>(h, s); break;
             case 2: if (seeded && h->scan_mode == 0 && (s.stride & 15) == 0 && s.stride >= 32) {
                         if (h->pair_cap > 0 && !h->pair_fused) { if (int rc = launch_pair_two_kernels(h, s)) return rc; }
-                        else launch_scan_paired(h, s);
+                        else launch_pair_stream(h, s);
                     } else if (seeded) launch_scan_seeded<2>(h, s);
                     else if (filtered) launch_scan_filtered<2>(h, s); else launch_scan<2>(h, s); break;
             default: launch_scan<3>(h, s); break;

@@ -614,10 +614,8 @@ __global__ __launch_bounds__(256) void k_scan_seeded(
 // table (tab2 / members2) in L2.  A read meets ~18 candidates (5k cells) instead of ~88 with the three
 // single-piece seeds, and ~1/330 of a 6.8M list instead of 1/38.
 //
-// Persistent workgroups of 1024 lanes (one per CU, 144 KB LDS: bitmaps + per-lane FIFO + events): each
-// wave takes 64-row chunks of the work list with a grid stride, so the bitmaps are loaded once per CU
-// and there is no tail of half-empty workgroups.  Verify, events and the replay of the ordered fold are
-// the ones of k_scan_seeded.
+// Two forms below: candidate lists + verify as two kernels (small whitelists), and k_pair_stream, which verifies
+// straight out of the buckets (any whitelist size).  Events and the replay of the ordered fold are those of k_scan_seeded.
 constexpr int kPairCount = 6;
 // Is the probe (pieces a < b, window ja = 4a - 2 + xi, jb = ja + 4(b - a) + di - 2) admissible?  With x = xi - 2 the
 // shift of piece a and delta = di - 2 the shift between the pieces, an alignment needs u >= max(0, -x) operations in
@@ -634,203 +632,10 @@ constexpr bool pair_probe_ok(int a, int b, int xi, int di) {
 }
 constexpr int kPairBmWords = 2048;                                // 65536 bits per pair
 constexpr int kPairTab = 65537;
-constexpr int kPairQCap = 16;                                     // FIFO entries per lane
-constexpr int kPairPop = 4;                                       // probes decoded per lane per step
-constexpr int kPairThreads = 1024;
-
-template <int K>
-__global__ __launch_bounds__(kPairThreads) void k_scan_paired(
-    const uint32_t *__restrict__ bitmap, const int32_t *__restrict__ tab2, const int32_t *__restrict__ members2,
-    const uint32_t *__restrict__ planes32, int n_wl,
-    const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
-    const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int tie,
-    int32_t *__restrict__ redo_list, int32_t *__restrict__ n_redo,
-    int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
-    static_assert(K == 2, "the pair lemma is stated for two edit operations");
-    __shared__ uint32_t bm[kPairCount * kPairBmWords];
-    __shared__ uint32_t fifo[kPairQCap][kPairThreads];
-    __shared__ uint32_t events[kMaxEvents][kPairThreads];
-    const int n_list = *n_list_ptr;
-    const int n_chunks = (n_list + 63) >> 6;
-    const int tid = threadIdx.x;
-    const int waves_per_block = kPairThreads / 64;
-    if ((int)blockIdx.x * waves_per_block >= n_chunks) return;    // workgroup-uniform: nothing to do here
-    for (int i = tid; i < kPairCount * kPairBmWords; i += kPairThreads) bm[i] = bitmap[i];
-    __syncthreads();
-    const uint32_t one = in_vgpr(kOne2);
-    constexpr int kFirst = kBcLen - K - 1;
-
-    for (int chunk = blockIdx.x * waves_per_block + (tid >> 6); chunk < n_chunks; chunk += gridDim.x * waves_per_block) {
-        const int slot = chunk * 64 + (tid & 63);
-        const bool active = slot < n_list;
-        const int r = list[active ? slot : n_list - 1];
-        const int len = ext_len[r];
-
-        uint32_t XH[kTextCols], XL[kTextCols];
-        uint64_t tc = 0;                                          // 2-bit codes of the text, column j at bits 2j
-        {
-            const RowBytes rb = load_row_packed(ext + (size_t)r * ext_stride);
-#pragma unroll
-            for (int j = 0; j < kTextCols; ++j) {
-                const uint32_t c = (j < len) ? rb.at(j) : (uint32_t)'A';   // padding can only add candidates
-                const uint32_t code = base_code(c);
-                XH[j] = (code & 2u) ? 0u : 0xFFFFFFFFu;
-                XL[j] = (code & 1u) ? 0u : 0xFFFFFFFFu;
-                tc |= (uint64_t)code << (2 * j);
-            }
-        }
-        uint32_t head = 0, tail = 0;
-        int nev = 0;
-        bool overflow = false;
-
-        auto verify_round = [&]() {                               // as in k_scan_seeded
-            const uint32_t cnt = tail - head;
-            const bool have = cnt != 0;
-            uint32_t i0 = fifo[head & (kPairQCap - 1)][tid], i1 = fifo[(head + 1) & (kPairQCap - 1)][tid];   // unconditional reads
-            i0 = have ? i0 : 0u;
-            i1 = cnt > 1 ? i1 : i0;
-            head += cnt > 1 ? 2u : (have ? 1u : 0u);
-            const uint32_t p0 = planes32[i0], p1 = planes32[i1];
-            const uint32_t bh = (p0 & 0xFFFFu) | (p1 << 16), bl = (p0 >> 16) | (p1 & 0xFFFF0000u);
-            PackedScan<K> A;
-            A.init();
-            uint32_t H = 0, P = 0;
-#pragma unroll
-            for (int j = 0; j < kTextCols; ++j) {
-                const uint32_t eq = BZ_LUT3(bh ^ XH[j], bl, XL[j], kTA & (kTB ^ kTC));
-                if (j == kTextCols - 1) A.template step<true>(eq, one);
-                else A.template step<false>(eq, one);
-                if (j >= kFirst) {
-                    if (((j - kFirst) & 1) == 0) P = A.R[K];
-                    else H = BZ_LUT3(H, P, A.R[K], kTA | kTB | kTC);
-                }
-            }
-            if (((kTextCols - 1 - kFirst) & 1) == 0) H |= P;
-            uint32_t cand = ((H >> 15) & 1u) | ((H >> 30) & 2u);
-            if (!have || !active) cand = 0;
-            if (cnt < 2) cand &= 1u;
-            while (cand) {                                        // rare, divergent, exact
-                const int k = __ffs(cand) - 1;
-                cand &= cand - 1;
-                const uint32_t p = k ? p1 : p0;
-                int ed, end;
-                exact_pair<K>(p & 0xFFFFu, p >> 16, XH, XL, len, tie, ed, end);
-                if (ed <= K) {                                    // a barcode met through several probes is recorded once
-                    const uint32_t ev = ((k ? i1 : i0) << 7) | ((uint32_t)ed << 5) | (uint32_t)end;
-                    bool seen = false;
-                    for (int a = 0; a < nev; ++a) seen = seen || events[a][tid] == ev;
-                    if (!seen) {
-                        if (nev < kMaxEvents) events[nev++][tid] = ev;
-                        else overflow = true;
-                    }
-                }
-            }
-        };
-
-        const uint32_t tlo_ = (uint32_t)tc, thi_ = (uint32_t)(tc >> 32);
-        // one pair of pieces (PA, PB static): probe the pair's bitmap for every admissible window pair, then turn
-        // the occupied buckets into FIFO candidates
-        auto do_pair = [&](auto pa_c, auto pb_c, auto p_c) {
-            constexpr int a = decltype(pa_c)::value, b = decltype(pb_c)::value, p = decltype(p_c)::value;
-            uint32_t mlo = 0, mhi = 0;                            // bit (5 xi + di) <=> windows (ja, jb) name an occupied bucket
-            // (opaque copies: otherwise the window codes of all six pairs are computed up front and spilled)
-            const uint32_t tlo = in_vgpr(tlo_), thi = in_vgpr(thi_);
-#pragma unroll
-            for (int xi = 0; xi < 9; ++xi) {
-#pragma unroll
-                for (int di = 0; di < 5; ++di) {
-                    const int ja = 4 * a - 2 + xi, jb = ja + 4 * (b - a) + di - 2;
-                    const bool ok = pair_probe_ok(a, b, xi, di);
-                    if (ok) {
-                        const uint32_t ca = 2 * ja + 8 <= 32 ? (tlo >> (2 * ja)) : 2 * ja >= 32 ? (thi >> ((2 * ja) & 31)) : __builtin_amdgcn_alignbit(thi, tlo, (2 * ja) & 31);
-                        const uint32_t cb = 2 * jb + 8 <= 32 ? (tlo >> (2 * jb)) : 2 * jb >= 32 ? (thi >> ((2 * jb) & 31)) : __builtin_amdgcn_alignbit(thi, tlo, (2 * jb) & 31);
-                        const uint32_t key = ((ca & 0xFFu) << 8) | (cb & 0xFFu);
-                        const uint32_t w = bm[p * kPairBmWords + (key >> 5)];
-                        const uint32_t bit = (w >> (key & 31u)) & 1u;
-                        const int pos = 5 * xi + di;
-                        if (pos < 32) mlo |= bit << (pos & 31); else mhi |= bit << ((pos - 32) & 31);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);                // at most five bitmap reads in flight: keeps the live set small
-            }
-            if (!active) { mlo = 0; mhi = 0; }
-            const int32_t *tp = tab2 + (size_t)p * kPairTab;
-            const int32_t *mp = members2 + (size_t)p * n_wl;
-            const uint64_t tcc = ((uint64_t)thi << 32) | tlo;
-            while (__builtin_amdgcn_ballot_w64((mlo | mhi) != 0) != 0) {
-                // straight-line on purpose (no divergent branches): every lane pops up to kPairPop hits and all the
-                // table look-ups of the step are in flight together; idle lanes read bucket 0 and drop it
-                int cur[kPairPop], end[kPairPop];
-                uint2 se[kPairPop];
-#pragma unroll
-                for (int q = 0; q < kPairPop; ++q) {
-                    const bool lo = mlo != 0;
-                    const uint32_t w = lo ? mlo : mhi;
-                    const bool h = w != 0;
-                    const int pos = (int)__builtin_ctz(w | 0x80000000u) + (lo ? 0 : 32);
-                    const uint32_t w2 = w & (w - 1u);
-                    mlo = lo ? w2 : mlo;
-                    mhi = lo ? mhi : w2;
-                    const int xi = (pos * 13) >> 6, di = pos - 5 * xi;          // pos / 5, pos % 5 for pos < 64
-                    const int ja = 4 * a - 2 + xi, jb = ja + 4 * (b - a) + di - 2;
-                    const uint32_t key = (((uint32_t)(tcc >> ((2 * ja) & 63)) & 0xFFu) << 8) | ((uint32_t)(tcc >> ((2 * jb) & 63)) & 0xFFu);
-                    const int32_t *e = tp + (h ? key : 0u);
-                    se[q] = make_uint2((uint32_t)e[0], (uint32_t)e[1]);
-                    cur[q] = h ? (int)se[q].x : 0; end[q] = h ? (int)se[q].y : 0;
-                }
-                for (;;) {
-                    bool any = false;
-#pragma unroll
-                    for (int q = 0; q < kPairPop; ++q) any = any || cur[q] < end[q];
-                    if (__builtin_amdgcn_ballot_w64(any) == 0) break;
-                    while (__builtin_amdgcn_ballot_w64((tail - head) > (uint32_t)(kPairQCap - kPairPop)) != 0) verify_round();
-                    int32_t mm[kPairPop];
-#pragma unroll
-                    for (int q = 0; q < kPairPop; ++q) mm[q] = mp[cur[q] < end[q] ? cur[q] : 0];
-#pragma unroll
-                    for (int q = 0; q < kPairPop; ++q) {                        // the slot at `tail` is free: unconditional store
-                        fifo[tail & (kPairQCap - 1)][tid] = (uint32_t)mm[q];
-                        tail += cur[q] < end[q] ? 1u : 0u;
-                        ++cur[q];
-                    }
-                }
-            }
-        };
-#define BZ_PAIR(A, B, P) do_pair(std::integral_constant<int, A>{}, std::integral_constant<int, B>{}, std::integral_constant<int, P>{})
-        BZ_PAIR(0, 1, 0); BZ_PAIR(0, 2, 1); BZ_PAIR(0, 3, 2); BZ_PAIR(1, 2, 3); BZ_PAIR(1, 3, 4); BZ_PAIR(2, 3, 5);
-#undef BZ_PAIR
-        while (__builtin_amdgcn_ballot_w64(tail != head) != 0) verify_round();
-
-        if (!active) continue;
-        if (overflow) {                                           // too many near matches: finish in whitelist order
-            redo_list[atomicAdd(n_redo, 1)] = r;
-            continue;
-        }
-        for (int a = 1; a < nev; ++a) {                           // events in whitelist order (insertion sort)
-            const uint32_t v = events[a][tid];
-            int b = a - 1;
-            while (b >= 0 && events[b][tid] > v) { events[b + 1][tid] = events[b][tid]; --b; }
-            events[b + 1][tid] = v;
-        }
-        int best = K, hit = kHitNone, hit_end = -1;
-        bool done = false;
-        uint32_t prev = 0xFFFFFFFFu;
-        for (int a = 0; a < nev; ++a) {
-            const uint32_t v = events[a][tid];
-            if (v == prev) continue;
-            prev = v;
-            fold_update((int)((v >> 5) & 3u), (int)(v & 31u), (int)(v >> 7), best, hit, hit_end, done);
-        }
-        hit_out[r] = hit >= 0 ? hit : -1;
-        ed_out[r] = (int8_t)best;
-        end_out[r] = (int8_t)(hit >= 0 ? hit_end : -1);
-        flags_out[r] = (uint8_t)(hit == kHitAmbiguous ? kFlagAmbig : 0u);
-    }
-}
 
 // ------------------------------------------------------------------------------------------
-// The same pair-seeded scan as two kernels (product path for max_ed == 2 while the candidate lists fit,
-// i.e. whitelists up to ~45k barcodes; above that k_scan_paired does both halves in one kernel):
+// The pair-seeded scan as two kernels (product path for max_ed == 2 while the candidate lists fit,
+// i.e. whitelists up to ~45k barcodes; above that k_pair_stream verifies straight out of the buckets):
 //
 //   k_pair_candidates : lane = row of the work list.  Needs the text's 2-bit codes only (2 VGPRs, no bit-plane
 //       masks), so 8 waves per SIMD hide the two dependent gathers per occupied bucket.  Probes the six LDS
@@ -853,7 +658,7 @@ constexpr int kCandPop = 8;                                       // hits decode
 // while it probes the next (the first version waited on every step of every pair: 63 us at 4.5 waves per SIMD with
 // nothing saturated).  Lanes with more than kCandPop hits in one pair (rare) finish them in a small loop.
 __global__ __launch_bounds__(kCandThreads) void k_pair_candidates(
-    const uint32_t *__restrict__ bitmap, const uint2 *__restrict__ tab8, const int32_t *__restrict__ members2, int n_wl,
+    const uint32_t *__restrict__ bitmap, const uint2 *__restrict__ tab8, const uint2 *__restrict__ members8, int n_wl,
     const uint8_t *__restrict__ ext, int ext_stride, const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr,
     uint32_t *__restrict__ cand, int cand_stride, int cap, uint32_t *__restrict__ cand_cnt) {
     __shared__ uint32_t bm[kPairCount * kPairBmWords];
@@ -886,7 +691,7 @@ __global__ __launch_bounds__(kCandThreads) void k_pair_candidates(
     uint32_t *out = cand + slot;
 
     // one bucket entry -> candidate slots (e.x = bucket size (saturating) | offset << 8, e.y = first member)
-    auto consume = [&](uint2 e, bool h, const int32_t *mp) {
+    auto consume = [&](uint2 e, bool h, const uint2 *mp) {
         const uint32_t n_mem = h ? (e.x & 0xFFu) : 0u;
         if (n_mem) {
             out[(size_t)min(cnt, (uint32_t)cap) * cand_stride] = e.y;          // row `cap` of the matrix is a dump row
@@ -894,7 +699,7 @@ __global__ __launch_bounds__(kCandThreads) void k_pair_candidates(
             if (n_mem > 1u) {                                     // rare for small whitelists
                 if (n_mem == 0xFFu) cnt = 0x40000000u;            // saturated size: let the ordered scan do this row
                 else for (uint32_t k = 1; k < n_mem; ++k) {
-                    out[(size_t)min(cnt, (uint32_t)cap) * cand_stride] = (uint32_t)mp[(e.x >> 8) + k];
+                    out[(size_t)min(cnt, (uint32_t)cap) * cand_stride] = mp[(e.x >> 8) + k].x;
                     ++cnt;
                 }
             }
@@ -904,7 +709,7 @@ __global__ __launch_bounds__(kCandThreads) void k_pair_candidates(
     bool h_prev[kCandPop];
 #pragma unroll
     for (int q = 0; q < kCandPop; ++q) { e_prev[q] = make_uint2(0u, 0u); h_prev[q] = false; }
-    const int32_t *mp_prev = members2;
+    const uint2 *mp_prev = members8;
 
     auto do_pair = [&](auto pa_c, auto pb_c, auto p_c) {
         constexpr int a = decltype(pa_c)::value, b = decltype(pb_c)::value, p = decltype(p_c)::value;
@@ -929,7 +734,7 @@ __global__ __launch_bounds__(kCandThreads) void k_pair_candidates(
         }
         if (!active) { mlo = 0; mhi = 0; }
         const uint2 *tp = tab8 + (size_t)p * 65536;
-        const int32_t *mp = members2 + (size_t)p * n_wl;
+        const uint2 *mp = members8 + (size_t)p * n_wl;
         const uint64_t tcc = ((uint64_t)thi << 32) | tlo;
         auto pop = [&](bool &h) -> uint32_t {                     // next hit of this lane -> its 16-bit key
             const bool lo = mlo != 0;
@@ -1080,6 +885,204 @@ __global__ __launch_bounds__(256) void k_pair_verify(
     for (int a = 0; a < nacc; ++a) {
         const uint32_t v = events[a][tid];
         if (v == 0xFFFFFFFFu) break;
+        fold_update((int)((v >> 5) & 3u), (int)(v & 31u), (int)(v >> 7), best, hit, hit_end, done);
+    }
+    hit_out[r] = hit >= 0 ? hit : -1;
+    ed_out[r] = (int8_t)best;
+    end_out[r] = (int8_t)(hit >= 0 ? hit_end : -1);
+    flags_out[r] = (uint8_t)(hit == kHitAmbiguous ? kFlagAmbig : 0u);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pair_stream: the pair-seeded scan for whitelists of ANY size (BASELINE's stress case: the full 10x list, 6.8M
+// barcodes, ~104 per bucket, ~13,600 candidates per row -- far too many to write down as lists).
+// lane = row.  Each lane walks its 131 admissible probes; a probe names a bucket = a contiguous run of
+// members8[] = {barcode index, planes32}, and the lane verifies the run two barcodes per round through the packed
+// automaton: one 8-byte gather per candidate, bit planes included, consecutive candidates of a bucket in the same
+// cache lines.  Pipeline per round: this round's two members were requested last round, the next bucket's bounds
+// two probes ahead.  Of the accepted candidates only the two smallest indices per distance class are kept (that is all
+// the ordered fold can consume, see below); they get their exact (ed, end) at the end, then the fold is replayed.
+constexpr int kStreamProbes = 136;                                // >= the 131 admissible probes
+
+struct PairProbeTable {                                           // entry = p | ja << 3 | jb << 8, flattened at compile time
+    uint32_t e[kStreamProbes];
+    int n;
+    constexpr PairProbeTable() : e(), n(0) {
+        const int pa[kPairCount] = {0, 0, 0, 1, 1, 2}, pb[kPairCount] = {1, 2, 3, 2, 3, 3};
+        for (int p = 0; p < kPairCount; ++p)
+            for (int xi = 0; xi < 9; ++xi)
+                for (int di = 0; di < 5; ++di)
+                    if (pair_probe_ok(pa[p], pb[p], xi, di)) {
+                        const int ja = 4 * pa[p] - 2 + xi, jb = ja + 4 * (pb[p] - pa[p]) + di - 2;
+                        e[n++] = (uint32_t)p | ((uint32_t)ja << 3) | ((uint32_t)jb << 8);
+                    }
+        for (int i = n; i < kStreamProbes; ++i) e[i] = 0;
+    }
+};
+__device__ const PairProbeTable kPairProbes{};
+static_assert(PairProbeTable().n <= kStreamProbes, "probe table too small");
+
+template <int K>
+__global__ __launch_bounds__(256) void k_pair_stream(
+    const int32_t *__restrict__ tab2, const uint2 *__restrict__ members8, const uint32_t *__restrict__ planes_of, int n_wl,
+    const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
+    const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int tie,
+    int32_t *__restrict__ redo_list, int32_t *__restrict__ n_redo,
+    int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
+    static_assert(K == 2, "the pair lemma is stated for two edit operations");
+    __shared__ uint32_t probes[kStreamProbes];
+    __shared__ uint32_t events[6][256];
+    const int n_list = *n_list_ptr;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x * 256 >= n_list) return;                  // workgroup-uniform
+    if (tid < kStreamProbes) probes[tid] = kPairProbes.e[tid];
+    __syncthreads();
+    const int n_probes = kPairProbes.n;
+    const int slot = blockIdx.x * 256 + tid;
+    if ((slot & ~63) >= n_list) return;                           // whole wave idle (wave-uniform)
+    const bool active = slot < n_list;
+    const int r = list[active ? slot : n_list - 1];
+    const int len = ext_len[r];
+
+    uint32_t XH[kTextCols], XL[kTextCols];
+    uint64_t tc = 0;                                              // 2-bit codes of the text, column j at bits 2j
+    {
+        const RowBytes rb = load_row_packed(ext + (size_t)r * ext_stride);
+#pragma unroll
+        for (int j = 0; j < kTextCols; ++j) {
+            const uint32_t c = (j < len) ? rb.at(j) : (uint32_t)'A';   // padding can only add candidates
+            const uint32_t code = base_code(c);
+            XH[j] = (code & 2u) ? 0u : 0xFFFFFFFFu;
+            XL[j] = (code & 1u) ? 0u : 0xFFFFFFFFu;
+            tc |= (uint64_t)code << (2 * j);
+        }
+    }
+    const uint32_t one = in_vgpr(kOne2);
+    constexpr int kFirst = kBcLen - K - 1;
+    // The fold (read_assignment.py:73-85) consumes at most TWO events of each distance class, and always the first two
+    // in whitelist order (a class is ignored for good once best_ed has dropped below it).  So the two smallest accepted
+    // indices per class decide the row, however many near matches a 6.8M-barcode list holds (~55 per row).  The class of
+    // a candidate = the lowest automaton level that accepts, exact for 20-column texts; shorter texts (padding columns
+    // can lower the level) keep every accepted index in one pool of two and hand the row on if a third shows up.
+    uint32_t keep[3][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { keep[c][0] = 0xFFFFFFFFu; keep[c][1] = 0xFFFFFFFFu; }
+    const bool full_text = len == kTextCols;
+    bool overflow = false;
+
+    // bucket of probe i as a [start, end) range of the flat members8 array (empty past the last probe / idle lanes)
+    auto bucket = [&](int i, uint32_t &bs, uint32_t &be) {
+        const bool ok = active && i < n_probes;
+        const uint32_t pe = probes[ok ? i : 0];
+        const uint32_t p = pe & 7u;
+        const uint32_t key = (((uint32_t)(tc >> (2 * ((pe >> 3) & 31u))) & 0xFFu) << 8) | ((uint32_t)(tc >> (2 * ((pe >> 8) & 31u))) & 0xFFu);
+        const int32_t *t = tab2 + (size_t)p * kPairTab + key;
+        const uint32_t s0 = (uint32_t)t[0], s1 = (uint32_t)t[1];
+        bs = ok ? p * (uint32_t)n_wl + s0 : 0u;
+        be = ok ? p * (uint32_t)n_wl + s1 : 0u;
+    };
+    uint32_t cur = 0, end = 0;                                    // rest of the current bucket
+    uint32_t nbs, nbe;                                            // the NEXT bucket's bounds (probe pi), already requested
+    int pi = 0;
+    bucket(pi, nbs, nbe);
+    // step to the next pair of members: inside the bucket, else into the next non-exhausted probe
+    auto advance = [&]() {
+        if (cur >= end) {                                         // (an empty bucket costs one idle round: rare on big lists)
+            cur = nbs; end = nbe;
+            ++pi;
+            bucket(pi, nbs, nbe);
+        }
+    };
+    advance();
+    uint2 m0 = members8[cur < end ? cur : 0], m1 = members8[cur + 1 < end ? cur + 1 : (cur < end ? cur : 0)];
+    bool v0 = cur < end, v1 = cur + 1 < end;
+    for (;;) {
+        const bool more = v0 || pi <= n_probes;                   // this lane still has members in hand or probes to open
+        if (__builtin_amdgcn_ballot_w64(active && more) == 0) break;
+        const uint2 c0 = m0, c1 = m1;
+        const bool a0 = v0, a1 = v1;
+        cur += 2;
+        advance();
+        m0 = members8[cur < end ? cur : 0];                       // next round's members fly under this round's automaton
+        m1 = members8[cur + 1 < end ? cur + 1 : (cur < end ? cur : 0)];
+        v0 = cur < end; v1 = cur + 1 < end;
+
+        const uint32_t q0 = c0.y, q1 = a1 ? c1.y : c0.y;
+        const uint32_t bh = (q0 & 0xFFFFu) | (q1 << 16), bl = (q0 >> 16) | (q1 & 0xFFFF0000u);
+        PackedScan<K> A;
+        A.init();
+        uint32_t H[K + 1], P[K + 1];                              // accept bits per level, two columns per op
+#pragma unroll
+        for (int d = 0; d <= K; ++d) { H[d] = 0; P[d] = 0; }
+#pragma unroll
+        for (int j = 0; j < kTextCols; ++j) {
+            const uint32_t eq = BZ_LUT3(bh ^ XH[j], bl, XL[j], kTA & (kTB ^ kTC));
+            if (j == kTextCols - 1) A.template step<true>(eq, one);
+            else A.template step<false>(eq, one);
+            if (j >= kFirst) {
+#pragma unroll
+                for (int d = 0; d <= K; ++d) {
+                    if (((j - kFirst) & 1) == 0) P[d] = A.R[d];
+                    else H[d] = BZ_LUT3(H[d], P[d], A.R[d], kTA | kTB | kTC);
+                }
+            }
+        }
+        if (((kTextCols - 1 - kFirst) & 1) == 0) {
+#pragma unroll
+            for (int d = 0; d <= K; ++d) H[d] |= P[d];
+        }
+        uint32_t acc = ((H[K] >> 15) & 1u) | ((H[K] >> 30) & 2u);
+        if (!a0) acc = 0;
+        if (!a1) acc &= 1u;
+        while (acc) {                                             // keep the two smallest indices of the candidate's class
+            const int b = __ffs(acc) - 1;
+            acc &= acc - 1;
+            const uint32_t idx = b ? c1.x : c0.x;
+            const uint32_t sh = b ? 31u : 15u;
+            int cls = ((H[0] >> sh) & 1u) ? 0 : ((H[1] >> sh) & 1u) ? 1 : 2;
+            if (!full_text) cls = 2;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (c != cls) continue;
+                if (idx == keep[c][0] || idx == keep[c][1]) continue;
+                if (!full_text && keep[c][1] != 0xFFFFFFFFu) overflow = true;   // a third index in the short-text pool
+                if (idx < keep[c][0]) { keep[c][1] = keep[c][0]; keep[c][0] = idx; }
+                else if (idx < keep[c][1]) keep[c][1] = idx;
+            }
+        }
+    }
+    // exact (ed, end) of the kept barcodes (at most six wave-wide rounds)
+    int nacc = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t idx = keep[c][t];
+            const bool have = idx != 0xFFFFFFFFu;
+            if (__builtin_amdgcn_ballot_w64(have) == 0) continue;
+            if (have) {
+                const uint32_t p = planes_of[idx];
+                int ed, end_i;
+                exact_pair<K>(p & 0xFFFFu, p >> 16, XH, XL, len, tie, ed, end_i);
+                if (ed <= K) events[nacc++][tid] = (idx << 7) | ((uint32_t)ed << 5) | (uint32_t)end_i;
+            }
+        }
+    }
+    if (!active) return;
+    if (overflow) {
+        redo_list[atomicAdd(n_redo, 1)] = r;
+        return;
+    }
+    for (int a = 1; a < nacc; ++a) {                              // events in whitelist order (insertion sort)
+        const uint32_t v = events[a][tid];
+        int b = a - 1;
+        while (b >= 0 && events[b][tid] > v) { events[b + 1][tid] = events[b][tid]; --b; }
+        events[b + 1][tid] = v;
+    }
+    int best = K, hit = kHitNone, hit_end = -1;
+    bool done = false;
+    for (int a = 0; a < nacc; ++a) {
+        const uint32_t v = events[a][tid];
         fold_update((int)((v >> 5) & 3u), (int)(v & 31u), (int)(v >> 7), best, hit, hit_end, done);
     }
     hit_out[r] = hit >= 0 ? hit : -1;

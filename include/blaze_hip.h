@@ -58,8 +58,9 @@ typedef struct bz_engine *bz_handle;
                                   seeds 5|5|6 for max_ed 2 (the first seeded scan, kept for comparison).
                                   Results are identical in all modes. */
 
-#define BZ_OPT_PAIR_FUSED 5    /* 1 = run the pair-seeded scan of mode 0 as ONE kernel (k_scan_paired) even when the
-                                  whitelist is small enough for the two-kernel form (testing; results identical) */
+#define BZ_OPT_PAIR_FUSED 5    /* 1 = run the pair-seeded scan of mode 0 as ONE kernel that verifies straight out of the
+                                  buckets (k_pair_stream, the form large whitelists take) even when the whitelist is
+                                  small enough for candidate lists + verify (testing; results identical) */
 
 #define BZ_OPT_PROFILE 6       /* 1 = record HIP events between the kernels of every run (bz_slot_timing's ms[]); off by
                                   default: each event costs ~6 us of idle GPU between two kernels */

@@ -643,12 +643,12 @@ constexpr int kPairTab = 65537;
 //       offset into members}: 96 % of the occupied buckets of a 5k list hold one barcode and need no second
 //       gather; entry = {size | offset << 8, first member}) and writes them to cand[s][slot] (s-th candidate of list slot `slot`: lanes of a wave write the
 //       same s at about the same time, so the 4-byte stores merge in L2 and k_pair_verify reads them coalesced).
-//   k_pair_verify<K>  : lane = row.  Two candidates per round through the packed K-error automaton; accepting
-//       candidates are only COLLECTED (distinct indices, <= kMaxEvents) and get their exact (ed, end) in a few
-//       rounds at the end (a true match is met through 3-6 pairs, and the divergent exact path used to run in
-//       almost every round of a wave); then the events are sorted by whitelist index and the reference's
-//       order-dependent fold is replayed.  Rows with more candidates than `cap` or more than kMaxEvents near
-//       matches go to redo_list (k_scan_filtered finishes them in whitelist order).
+//   k_pair_verify<K>  : lane = row.  Two candidates per round through the packed K-error automaton; of the accepting
+//       candidates only the two smallest indices per distance class are kept (all the ordered fold can consume, see
+//       k_pair_stream) and get their exact (ed, end) in at most six rounds at the end (a true match is met through 3-6
+//       pairs, and the divergent exact path used to run in almost every round of a wave); then the events are sorted
+//       by whitelist index and the reference's order-dependent fold is replayed.  Rows with more candidates than `cap`
+//       go to redo_list (k_scan_filtered finishes them in whitelist order).
 constexpr uint32_t kCandOverflow = 0xFFFFFFFFu;
 constexpr int kCandThreads = 1024;
 constexpr int kCandPop = 8;                                       // hits decoded per lane and pair in the straight-line part
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(256) void k_pair_verify(
     const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int tie,
     int32_t *__restrict__ redo_list, int32_t *__restrict__ n_redo,
     int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
-    __shared__ uint32_t events[kMaxEvents][256];
+    __shared__ uint32_t events[6][256];
     const int n_list = *n_list_ptr;
     const int tid = threadIdx.x;
     const int slot = blockIdx.x * blockDim.x + tid;
@@ -807,7 +807,10 @@ __global__ __launch_bounds__(256) void k_pair_verify(
     }
     const uint32_t one = in_vgpr(kOne2);
     constexpr int kFirst = kBcLen - K - 1;
-    int nacc = 0;                                                 // distinct accepted barcode indices in events[][tid]
+    uint32_t keep[3][2];                                          // two smallest accepted indices per distance class (see k_pair_stream)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { keep[c][0] = 0xFFFFFFFFu; keep[c][1] = 0xFFFFFFFFu; }
+    const bool full_text = len == kTextCols;
     const uint32_t *cp = cand + slot;
 
     // candidates of round k: slots 2k and 2k+1 (an odd tail repeats the first).  Two-deep pipeline: the candidate
@@ -832,41 +835,62 @@ __global__ __launch_bounds__(256) void k_pair_verify(
         const uint32_t bh = (q0 & 0xFFFFu) | (q1 << 16), bl = (q0 >> 16) | (q1 & 0xFFFF0000u);
         PackedScan<K> A;
         A.init();
-        uint32_t H = 0, P = 0;
+        uint32_t H[K + 1], P[K + 1];                              // accept bits per level, two columns per op
+#pragma unroll
+        for (int d = 0; d <= K; ++d) { H[d] = 0; P[d] = 0; }
 #pragma unroll
         for (int j = 0; j < kTextCols; ++j) {
             const uint32_t eq = BZ_LUT3(bh ^ XH[j], bl, XL[j], kTA & (kTB ^ kTC));
             if (j == kTextCols - 1) A.template step<true>(eq, one);
             else A.template step<false>(eq, one);
             if (j >= kFirst) {
-                if (((j - kFirst) & 1) == 0) P = A.R[K];
-                else H = BZ_LUT3(H, P, A.R[K], kTA | kTB | kTC);
+#pragma unroll
+                for (int d = 0; d <= K; ++d) {
+                    if (((j - kFirst) & 1) == 0) P[d] = A.R[d];
+                    else H[d] = BZ_LUT3(H[d], P[d], A.R[d], kTA | kTB | kTC);
+                }
             }
         }
-        if (((kTextCols - 1 - kFirst) & 1) == 0) H |= P;
-        uint32_t acc = ((H >> 15) & 1u) | ((H >> 30) & 2u);
+        if (((kTextCols - 1 - kFirst) & 1) == 0) {
+#pragma unroll
+            for (int d = 0; d <= K; ++d) H[d] |= P[d];
+        }
+        uint32_t acc = ((H[K] >> 15) & 1u) | ((H[K] >> 30) & 2u);
         if (2 * k >= cnt) acc = 0;
         if (2 * k + 1 >= cnt) acc &= 1u;
-        while (acc) {                                             // collect distinct accepted indices (cheap; exact path later)
+        while (acc) {                                             // keep the two smallest indices of the candidate's class
             const int b = __ffs(acc) - 1;
             acc &= acc - 1;
             const uint32_t idx = b ? c1 : c0;
-            bool seen = false;
-            for (int a = 0; a < nacc; ++a) seen = seen || events[a][tid] == idx;
-            if (!seen) {
-                if (nacc < kMaxEvents) events[nacc++][tid] = idx;
-                else overflow = true;
+            const uint32_t sh = b ? 31u : 15u;
+            int cls = ((H[0] >> sh) & 1u) ? 0 : (K >= 1 && ((H[K >= 1 ? 1 : 0] >> sh) & 1u)) ? 1 : 2;
+            if (!full_text) cls = 2;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (c != cls) continue;
+                if (idx == keep[c][0] || idx == keep[c][1]) continue;
+                if (!full_text && keep[c][1] != 0xFFFFFFFFu) overflow = true;   // a third index in the short-text pool
+                if (idx < keep[c][0]) { keep[c][1] = keep[c][0]; keep[c][0] = idx; }
+                else if (idx < keep[c][1]) keep[c][1] = idx;
             }
         }
     }
-    // exact (ed, end) of the accepted barcodes: a few wave-wide rounds
-    for (int a = 0; __builtin_amdgcn_ballot_w64(a < nacc) != 0; ++a) {
-        if (a < nacc) {
+    // exact (ed, end) of the kept barcodes: compacted per lane, then as many wave-wide rounds as the fullest lane needs
+    int nkept = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            if (keep[c][t] != 0xFFFFFFFFu) events[nkept++][tid] = keep[c][t];
+    }
+    int nacc = 0;
+    for (int a = 0; __builtin_amdgcn_ballot_w64(a < nkept) != 0; ++a) {
+        if (a < nkept) {
             const uint32_t idx = events[a][tid];
             const uint32_t p = planes32[idx];
             int ed, end;
             exact_pair<K>(p & 0xFFFFu, p >> 16, XH, XL, len, tie, ed, end);
-            events[a][tid] = ed <= K ? ((idx << 7) | ((uint32_t)ed << 5) | (uint32_t)end) : 0xFFFFFFFFu;   // rejected: sorts last
+            if (ed <= K) events[nacc++][tid] = (idx << 7) | ((uint32_t)ed << 5) | (uint32_t)end;   // nacc <= a: in place
         }
     }
     if (!active) return;
@@ -884,7 +908,6 @@ __global__ __launch_bounds__(256) void k_pair_verify(
     bool done = false;
     for (int a = 0; a < nacc; ++a) {
         const uint32_t v = events[a][tid];
-        if (v == 0xFFFFFFFFu) break;
         fold_update((int)((v >> 5) & 3u), (int)(v & 31u), (int)(v >> 7), best, hit, hit_end, done);
     }
     hit_out[r] = hit >= 0 ? hit : -1;
@@ -1051,21 +1074,22 @@ __global__ __launch_bounds__(256) void k_pair_stream(
             }
         }
     }
-    // exact (ed, end) of the kept barcodes (at most six wave-wide rounds)
-    int nacc = 0;
+    // exact (ed, end) of the kept barcodes: compacted per lane, then as many wave-wide rounds as the fullest lane needs
+    int nkept = 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const uint32_t idx = keep[c][t];
-            const bool have = idx != 0xFFFFFFFFu;
-            if (__builtin_amdgcn_ballot_w64(have) == 0) continue;
-            if (have) {
-                const uint32_t p = planes_of[idx];
-                int ed, end_i;
-                exact_pair<K>(p & 0xFFFFu, p >> 16, XH, XL, len, tie, ed, end_i);
-                if (ed <= K) events[nacc++][tid] = (idx << 7) | ((uint32_t)ed << 5) | (uint32_t)end_i;
-            }
+        for (int t = 0; t < 2; ++t)
+            if (keep[c][t] != 0xFFFFFFFFu) events[nkept++][tid] = keep[c][t];
+    }
+    int nacc = 0;
+    for (int a = 0; __builtin_amdgcn_ballot_w64(a < nkept) != 0; ++a) {
+        if (a < nkept) {
+            const uint32_t idx = events[a][tid];
+            const uint32_t p = planes_of[idx];
+            int ed, end_i;
+            exact_pair<K>(p & 0xFFFFu, p >> 16, XH, XL, len, tie, ed, end_i);
+            if (ed <= K) events[nacc++][tid] = (idx << 7) | ((uint32_t)ed << 5) | (uint32_t)end_i;   // nacc <= a: in place
         }
     }
     if (!active) return;

@@ -755,6 +755,46 @@ int bz_edit_distance(bz_handle h, const char *a, int la, const char *b, int lb, 
     return pair_call(h, a, la, b, lb, max_ed, 1, nullptr);
 }
 
+// ---- empty-drop test: which strings of A are far from every string of B (main.py:244-256, :269-281) -------------
+int bz_far_from_all(bz_handle h, const char *a_bytes, const int64_t *a_off, int64_t n_a, const char *b_bytes, const int64_t *b_off,
+                    int64_t n_b, int min_ed, uint8_t *far_out) {
+    if (int rc = use(h)) return rc;
+    if (n_a < 0 || n_b < 0 || !a_off || !b_off || (n_a > 0 && (!a_bytes || !far_out)) || (n_b > 0 && !b_bytes))
+        return fail(BZ_E_ARG, "bad far-from-all arguments");
+    if (min_ed < 1 || min_ed > BZ_EXT_MAX) return fail(BZ_E_ARG, "min_ed %d outside 1..%d", min_ed, BZ_EXT_MAX);
+    if (n_a > (int64_t)1 << 30 || n_b > (int64_t)1 << 30) return fail(BZ_E_LIMIT, "more than 2^30 strings");
+    for (int64_t k = 0; k < n_a; ++k)
+        if (a_off[k + 1] < a_off[k] || a_off[k + 1] - a_off[k] > BZ_EXT_MAX) return fail(BZ_E_LIMIT, "string %lld of A: length outside 0..%d", (long long)k, BZ_EXT_MAX);
+    for (int64_t k = 0; k < n_b; ++k)
+        if (b_off[k + 1] < b_off[k] || b_off[k + 1] - b_off[k] > BZ_EXT_MAX) return fail(BZ_E_LIMIT, "string %lld of B: length outside 0..%d", (long long)k, BZ_EXT_MAX);
+    if (n_a == 0) return BZ_OK;
+    std::vector<int64_t> ao(n_a + 1), bo(n_b + 1);
+    for (int64_t k = 0; k <= n_a; ++k) ao[k] = a_off[k] - a_off[0];
+    for (int64_t k = 0; k <= n_b; ++k) bo[k] = b_off[k] - b_off[0];
+    uint8_t *d_a = nullptr, *d_b = nullptr, *d_far = nullptr;
+    int64_t *d_ao = nullptr, *d_bo = nullptr;
+    int rc = BZ_OK;
+    auto step = [&](hipError_t e) { if (e != hipSuccess && rc == BZ_OK) rc = fail(BZ_E_HIP, "%s", hipGetErrorString(e)); };
+    step(hipMalloc(&d_a, std::max<int64_t>(ao[n_a], 1))); step(hipMalloc(&d_b, std::max<int64_t>(bo[n_b], 1)));
+    step(hipMalloc(&d_ao, (n_a + 1) * sizeof(int64_t))); step(hipMalloc(&d_bo, (n_b + 1) * sizeof(int64_t)));
+    step(hipMalloc(&d_far, n_a));
+    if (rc == BZ_OK) {
+        if (ao[n_a]) step(hipMemcpy(d_a, a_bytes + a_off[0], ao[n_a], hipMemcpyHostToDevice));
+        if (bo[n_b]) step(hipMemcpy(d_b, b_bytes + b_off[0], bo[n_b], hipMemcpyHostToDevice));
+        step(hipMemcpy(d_ao, ao.data(), (n_a + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+        step(hipMemcpy(d_bo, bo.data(), (n_b + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    if (rc == BZ_OK) {
+        hipLaunchKernelGGL(bz::k_far_from_all, dim3((unsigned)((n_a + 255) / 256)), dim3(256), 0, h->slot[0].stream, d_a, d_ao, (int)n_a, d_b, d_bo,
+                           (int)n_b, min_ed, d_far);
+        step(hipGetLastError());
+        step(hipStreamSynchronize(h->slot[0].stream));
+        step(hipMemcpy(far_out, d_far, n_a, hipMemcpyDeviceToHost));
+    }
+    hipFree(d_a); hipFree(d_b); hipFree(d_ao); hipFree(d_bo); hipFree(d_far);
+    return rc;
+}
+
 int bz_counts_reset(bz_handle h) {
     if (int rc = use(h)) return rc;
     if (h->n_wl < 0) return fail(BZ_E_STATE, "no whitelist");

@@ -1221,6 +1221,28 @@ __global__ void k_scan_generic(const uint8_t *__restrict__ wl_bytes, const int64
     }
 }
 
+// far[i] = 1 iff every string of set B is at global edit distance >= min_ed from A[i]: the test of the empty-drop list,
+// `min([edit_distance(k, x, max_ed=5) for x in cells_bc.keys()]) >= 5` (main.py:249-250, :274-275).  lane = A[i]; the B
+// strings are wave-uniform (scalar loads), a lane stops at the first close one.  Lengths <= kGenericMax (host checks).
+__global__ __launch_bounds__(256) void k_far_from_all(const uint8_t *__restrict__ a_bytes, const int64_t *__restrict__ a_off, int n_a,
+                                                     const uint8_t *__restrict__ b_bytes, const int64_t *__restrict__ b_off, int n_b,
+                                                     int min_ed, uint8_t *__restrict__ far) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_a) return;
+    const uint8_t *a = a_bytes + a_off[i];
+    const int la = (int)(a_off[i + 1] - a_off[i]);
+    uint8_t mine[kGenericMax];
+    for (int k = 0; k < la; ++k) mine[k] = a[k];
+    bool is_far = true;
+    for (int k = 0; k < n_b && is_far; ++k) {
+        const int64_t o = b_off[k];
+        const int lb = (int)(b_off[k + 1] - o);
+        if (abs(la - lb) >= min_ed) continue;                  // the length gap alone is a lower bound
+        if (dev_edit_distance(mine, la, b_bytes + o, lb, min_ed - 1) < min_ed) is_far = false;
+    }
+    far[i] = is_far ? 1 : 0;
+}
+
 __global__ void k_pair(const uint8_t *a, int la, const uint8_t *b, int lb, int max_ed, int tie, int global_mode, int32_t *out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (global_mode) { out[0] = dev_edit_distance(a, la, b, lb, max_ed); out[1] = -1; }

@@ -1,0 +1,125 @@
+"""Stage 2's empty-droplet barcode list on MI355X: drop-in for
+/root/reference/blaze/main.py:151-284 `get_bc_whitelist`, same arguments and return values.
+
+What changed underneath: the loop of :248-255 / :273-280,
+
+    for k in ept_bc_candidate:
+        if min([edit_distance(k, x, max_ed=5) for x in cells_bc.keys()]) >= 5: ept_bc.append(k)
+        if len(ept_bc) > 2000: break
+
+(candidates x cells third-party `edit_distance` calls from Python) is one device launch per block of
+candidates (bz_far_from_all, blaze_amd/csrc/scan_kernels.h:k_far_from_all); the order of the
+candidates, the `>` in the stop rule (2001 barcodes come out, as in test/expect_output/test_emtpy_bc_list.csv)
+and everything around the loop are kept.  The knee plot (:286-302, matplotlib) is not drawn: `out_plot_fn` is
+accepted and ignored.  No CPU scoring path: without libblaze_hip.so and a GPU the empty-drop list raises.
+"""
+from __future__ import annotations
+
+import io
+import logging
+import zipfile
+
+import numpy as np
+
+from . import _lib, helper
+from .engine import pack_whitelist
+
+logger = logging.getLogger(__name__)
+
+DEFAULT_EMPTY_DROP_MIN_ED = 5      # config.py:64
+DEFAULT_EMPTY_DROP_NUM = 2000      # config.py:65
+_BLOCK = 4096                      # candidates per device launch
+
+
+def default_count_threshold_calculation(count_array, exp_cells):          # config.py:52-54
+    top_count = np.sort(count_array)[::-1][:exp_cells]
+    return np.quantile(top_count, 0.95) / 20
+
+
+def high_sensitivity_threshold_calculation(count_array, exp_cells):       # config.py:56-58
+    top_count = np.sort(count_array)[::-1][:exp_cells]
+    return np.quantile(top_count, 0.95) / 200
+
+
+def far_from_all(engine, candidates, cells, min_ed=DEFAULT_EMPTY_DROP_MIN_ED):
+    """bool array: candidates[i] is at global edit distance >= min_ed from every string of `cells`."""
+    out = np.zeros(len(candidates), dtype=np.uint8)
+    if not len(candidates):
+        return out.astype(bool)
+    a, ao = pack_whitelist(candidates)
+    b, bo = pack_whitelist(cells)
+    _lib.check(_lib.load().bz_far_from_all(engine._h, a.ctypes.data, ao.ctypes.data, len(candidates), b.ctypes.data,
+                                           bo.ctypes.data, len(cells), int(min_ed), out.ctypes.data))
+    return out.astype(bool)
+
+
+def empty_drop_list(candidates, cells, engine=None, min_ed=DEFAULT_EMPTY_DROP_MIN_ED, max_n=DEFAULT_EMPTY_DROP_NUM):
+    """main.py:248-255: candidates in order, keep those far from every cell barcode, stop once MORE than max_n are kept."""
+    if engine is None:
+        from .read_assignment import get_engine
+        engine = get_engine()
+    candidates, cells = list(candidates), list(cells)
+    if candidates and not cells:
+        raise ValueError("min() arg is an empty sequence")       # what the reference's min([]) raises
+    ept_bc = []
+    for lo in range(0, len(candidates), _BLOCK):
+        block = candidates[lo:lo + _BLOCK]
+        for k, far in zip(block, far_from_all(engine, block, cells, min_ed)):
+            if far:
+                ept_bc.append(k)
+            if len(ept_bc) > max_n:
+                return ept_bc
+    return ept_bc
+
+
+def get_bc_whitelist(raw_bc_count, full_bc_whitelist=None, exp_cells=None, count_t=None, force_cell_n=None,
+                     high_sensitivity_mode=False, output_empty=True, empty_max_count=np.inf,
+                     out_plot_fn='knee_plot.png', args=None, engine=None):
+    """Cell barcodes {barcode: count} and the empty-droplet barcode list, as the reference's function of the same name."""
+    if args:
+        full_bc_whitelist = args.full_bc_whitelist
+        exp_cells = args.expect_cells
+        count_t = args.count_threshold
+        high_sensitivity_mode = args.high_sensitivity_mode
+        out_plot_fn = args.out_plot_fn
+        empty_max_count = args.empty_max_count
+        force_cell_n = args.force_cells
+        output_empty = args.do_empty_drops_output
+    percentile_count_thres = high_sensitivity_threshold_calculation if high_sensitivity_mode \
+        else default_count_threshold_calculation
+
+    whole_whitelist = []
+    if full_bc_whitelist.endswith('.zip'):
+        with zipfile.ZipFile(full_bc_whitelist) as zf:
+            assert len(zf.namelist()) == 1
+            with io.TextIOWrapper(zf.open(zf.namelist()[0]), encoding="utf-8") as f:
+                for line in f:
+                    whole_whitelist.append(line.strip())
+    else:
+        with open(full_bc_whitelist, 'r') as f:
+            for line in f:
+                whole_whitelist.append(line.strip())
+    whole_whitelist = set(whole_whitelist)
+    raw_bc_count = {k: v for k, v in raw_bc_count.items() if k in whole_whitelist}
+
+    if force_cell_n:
+        if force_cell_n > len(raw_bc_count):
+            logger.warning(helper.warning_msg(
+                f"force_cells ({force_cell_n}) is larger than the number of unique barcodes found in the data "
+                f"({len(raw_bc_count)})."))
+            count_t = 0
+        else:
+            count_t = sorted(list(raw_bc_count.values()))[-force_cell_n]
+    if count_t is not None:
+        cells_bc = {k: v for k, v in raw_bc_count.items() if v >= count_t}
+    elif exp_cells:
+        t = percentile_count_thres(list(raw_bc_count.values()), exp_cells)
+        cells_bc = {k: v for k, v in raw_bc_count.items() if v > t}
+    else:
+        raise ValueError('Invalid value of count_t and/or exp_cells.')
+    if not output_empty:
+        return cells_bc, []
+    logger.info("Creating emtpy droplets barcode list...")
+    ept_bc_max_count = min(min(cells_bc.values()), empty_max_count)
+    ept_bc_candidate = [k for k, v in raw_bc_count.items() if v < ept_bc_max_count]
+    return cells_bc, empty_drop_list(ept_bc_candidate, cells_bc.keys(), engine)

@@ -125,6 +125,14 @@ int bz_slot_timing(bz_handle h, int slot, float ms[8], int64_t counts[8]);
 int bz_sub_edit_distance(bz_handle h, const char *a, int la, const char *b, int lb, int max_ed, int *end_idx);
 int bz_edit_distance(bz_handle h, const char *a, int la, const char *b, int lb, int max_ed);
 
+/* ---- empty-drop test (stage 2, main.py:244-256 and :269-281) --------------------------------------------- */
+/* far_out[i] = 1 iff every string of B is at global edit distance >= min_ed from string i of A, i.e.
+ * `min([edit_distance(k, x, max_ed=min_ed) for x in cells_bc.keys()]) >= min_ed` of main.py:250,275 for k = A[i]
+ * (A = empty-drop candidates, B = the selected cell barcodes, min_ed = DEFAULT_EMPTY_DROP_MIN_ED = 5, config.py:64).
+ * Strings are given as in bz_set_whitelist (bytes + n+1 offsets), each at most BZ_EXT_MAX long.  Synchronous. */
+int bz_far_from_all(bz_handle h, const char *a_bytes, const int64_t *a_off, int64_t n_a, const char *b_bytes,
+                    const int64_t *b_off, int64_t n_b, int min_ed, uint8_t *far_out);
+
 /* ---- whole step 3 over files ------------------------------------------------------------------------ */
 /* Native host pipeline = assign_read's batch loop (read_assignment.py:253-330) with its generator
  * (:138-181, helper.py:275-301), per-batch epilogue (:87-99, :214-247) and ordered concatenation

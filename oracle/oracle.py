@@ -63,6 +63,8 @@ def lib():
             L.orc_match_rows.argtypes = [c_p, c_int, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_i64,
                                          c_int, c_int, c_int, c_p, c_p, c_p, c_p]
             L.orc_match_rows.restype = None
+            L.orc_far_from_all.argtypes = [c_p, c_p, c_int, c_i64, c_p, c_p, c_int, c_i64, c_int, c_p]
+            L.orc_far_from_all.restype = None
             _lib = L
     return _lib
 
@@ -235,3 +237,36 @@ def match_rows(ext, ext_len, bc_off, bc_len, whitelist, max_ed, tie_rule=TIE_LEF
         with ThreadPoolExecutor(threads) as ex:     # ctypes drops the GIL during the call
             list(ex.map(lambda s: run(*s), spans))
     return hit, ed, end, flag
+
+
+def _records(strings):
+    enc = [_b(x) for x in strings]
+    stride = max([len(x) for x in enc] + [1])
+    buf = np.zeros((len(enc), stride), dtype=np.uint8)
+    for k, x in enumerate(enc):
+        buf[k, :len(x)] = np.frombuffer(x, dtype=np.uint8)
+    return buf, np.array([len(x) for x in enc], dtype=np.int32), stride
+
+
+def far_from_all(candidates, cells, min_ed=5):
+    """main.py:249-250: [min(edit_distance(k, x, min_ed) for x in cells) >= min_ed for k in candidates]."""
+    candidates, cells = list(candidates), list(cells)
+    far = np.zeros(len(candidates), dtype=np.uint8)
+    if candidates:
+        a, al, ast = _records(candidates)
+        b, bl, bst = _records(cells)
+        lib().orc_far_from_all(a.ctypes.data, al.ctypes.data, ast, len(candidates), b.ctypes.data, bl.ctypes.data, bst,
+                               len(cells), int(min_ed), far.ctypes.data)
+    return far.astype(bool)
+
+
+def empty_drop_list(candidates, cells, min_ed=5, max_n=2000):
+    """main.py:248-255, literally: keep far candidates in order, stop once MORE than max_n are kept."""
+    cells = list(cells)
+    ept_bc = []
+    for k in candidates:
+        if far_from_all([k], cells, min_ed)[0]:
+            ept_bc.append(k)
+        if len(ept_bc) > max_n:
+            break
+    return ept_bc

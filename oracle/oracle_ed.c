@@ -163,3 +163,20 @@ void orc_match_rows(const uint8_t *ext, int ext_stride, const uint8_t *ext_len,
                       wl, wl_off, n_wl, max_ed, tie_rule, shortcut,
                       hit + r, ed_out + r, end_out + r, flag + r);
 }
+
+
+/* Empty-drop test of main.py:249-250 / :274-275 for a block of candidates:
+ * far[i] = ( min over cells x of edit_distance(cand[i], x, max_ed=min_ed) >= min_ed ).
+ * Strings are fixed-stride records (cand: n_cand x cand_stride with lengths cand_len[i], likewise cells). */
+void orc_far_from_all(const char *cand, const int *cand_len, int cand_stride, long long n_cand,
+                      const char *cells, const int *cell_len, int cell_stride, long long n_cells,
+                      int min_ed, unsigned char *far) {
+    for (long long i = 0; i < n_cand; ++i) {
+        int best = min_ed + 1;
+        for (long long k = 0; k < n_cells; ++k) {
+            int d = orc_edit_distance(cand + i * cand_stride, cand_len[i], cells + k * cell_stride, cell_len[k], min_ed);
+            if (d < best) best = d;
+        }
+        far[i] = (n_cells > 0 && best >= min_ed) ? 1 : 0;
+    }
+}

@@ -18,6 +18,7 @@
 
 #include "../../include/blaze_hip.h"
 #include "scan_kernels.h"
+#include "stage1_kernels.h"
 #include "host_io.h"
 
 namespace {
@@ -753,6 +754,50 @@ int bz_sub_edit_distance(bz_handle h, const char *a, int la, const char *b, int 
 }
 int bz_edit_distance(bz_handle h, const char *a, int la, const char *b, int lb, int max_ed) {
     return pair_call(h, a, la, b, lb, max_ed, 1, nullptr);
+}
+
+// ---- stage 1: putative barcode search per read (polyT_adaptor_finder.py class Read) -----------------------------
+int bz_putative_bc(bz_handle h, const char *seq, const char *qual, const int64_t *off, int64_t n, int kit_5prime, int umi_len,
+                   int32_t *pass_code, int8_t *strand, int32_t *raw_bc_start, int32_t *min_q, int32_t *polyT_end) {
+    if (int rc = use(h)) return rc;
+    if (n < 0 || !off || (n > 0 && (!seq || !qual || !pass_code || !strand || !raw_bc_start || !min_q || !polyT_end)))
+        return fail(BZ_E_ARG, "bad putative-bc arguments");
+    if (umi_len < 0 || umi_len > 64) return fail(BZ_E_ARG, "umi_len %d outside 0..64", umi_len);
+    if (n > (int64_t)1 << 30) return fail(BZ_E_LIMIT, "more than 2^30 reads");
+    for (int64_t k = 0; k < n; ++k) {
+        if (off[k + 1] < off[k]) return fail(BZ_E_ARG, "offsets not monotone at %lld", (long long)k);
+        if (off[k + 1] - off[k] > (int64_t)1 << 30) return fail(BZ_E_LIMIT, "read %lld longer than 2^30", (long long)k);
+    }
+    if (n == 0) return BZ_OK;
+    const int64_t total = off[n] - off[0];
+    std::vector<int64_t> o(n + 1);
+    for (int64_t k = 0; k <= n; ++k) o[k] = off[k] - off[0];
+    uint8_t *d_seq = nullptr, *d_qual = nullptr;
+    int64_t *d_off = nullptr;
+    int32_t *d_i32 = nullptr;
+    int8_t *d_strand = nullptr;
+    int rc = BZ_OK;
+    auto step = [&](hipError_t e) { if (e != hipSuccess && rc == BZ_OK) rc = fail(BZ_E_HIP, "%s", hipGetErrorString(e)); };
+    step(hipMalloc(&d_seq, std::max<int64_t>(total, 1))); step(hipMalloc(&d_qual, std::max<int64_t>(total, 1)));
+    step(hipMalloc(&d_off, (n + 1) * sizeof(int64_t))); step(hipMalloc(&d_i32, 4 * n * sizeof(int32_t))); step(hipMalloc(&d_strand, n));
+    hipStream_t st = h->slot[0].stream;
+    if (rc == BZ_OK) {
+        if (total) { step(hipMemcpyAsync(d_seq, seq + off[0], total, hipMemcpyHostToDevice, st)); step(hipMemcpyAsync(d_qual, qual + off[0], total, hipMemcpyHostToDevice, st)); }
+        step(hipMemcpyAsync(d_off, o.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    }
+    if (rc == BZ_OK) {
+        hipLaunchKernelGGL(bz::k_stage1, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_seq, d_qual, d_off, (int)n, kit_5prime ? 1 : 0, umi_len,
+                           h->tie_rule, d_i32, d_strand, d_i32 + n, d_i32 + 2 * n, d_i32 + 3 * n);
+        step(hipGetLastError());
+        step(hipMemcpyAsync(pass_code, d_i32, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        step(hipMemcpyAsync(raw_bc_start, d_i32 + n, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        step(hipMemcpyAsync(min_q, d_i32 + 2 * n, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        step(hipMemcpyAsync(polyT_end, d_i32 + 3 * n, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        step(hipMemcpyAsync(strand, d_strand, n, hipMemcpyDeviceToHost, st));
+        step(hipStreamSynchronize(st));
+    }
+    hipFree(d_seq); hipFree(d_qual); hipFree(d_off); hipFree(d_i32); hipFree(d_strand);
+    return rc;
 }
 
 // ---- empty-drop test: which strings of A are far from every string of B (main.py:244-256, :269-281) -------------

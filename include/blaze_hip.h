@@ -125,6 +125,19 @@ int bz_slot_timing(bz_handle h, int slot, float ms[8], int64_t counts[8]);
 int bz_sub_edit_distance(bz_handle h, const char *a, int la, const char *b, int lb, int max_ed, int *end_idx);
 int bz_edit_distance(bz_handle h, const char *a, int la, const char *b, int lb, int max_ed);
 
+/* ---- stage 1: putative barcode search (polyT_adaptor_finder.py class Read, main.py:43-106) ------------------ */
+/* Per read r = seq[off[r] .. off[r+1]) with its quality string at the same offsets of `qual`:
+ *   pass_code     adaptor_polyT_pass of polyT_adaptor_finder.py:222-244: 0 found, 1 none, 2 both strands, 10 several
+ *                 adaptors; -1 where the reference raises (empty quality slice, :278)
+ *   strand        '+' / '-' or 0 (:261), raw_bc_start the adaptor end (:260), min_q raw_bc_min_q (:278),
+ *   polyT_end     polyT_trimming_idx (:344-379; 0 when pass_code != 0)
+ * kit_5prime = 0 for kits 3v2 / 3v3 / 3v4 (find_adaptor_3_prime, :85-164), 1 otherwise (find_adapter_5_prime, :43-83);
+ * umi_len as parser.py:180-191.  The end-index tie rule of sub_edit_distance is BZ_OPT_TIE_RULE (it decides
+ * raw_bc_start when several adaptor ends tie).  Every CSV field of main.py:96-105 is a slice of the read at these
+ * numbers (the host slices).  Synchronous. */
+int bz_putative_bc(bz_handle h, const char *seq, const char *qual, const int64_t *off, int64_t n, int kit_5prime, int umi_len,
+                   int32_t *pass_code, int8_t *strand, int32_t *raw_bc_start, int32_t *min_q, int32_t *polyT_end);
+
 /* ---- empty-drop test (stage 2, main.py:244-256 and :269-281) --------------------------------------------- */
 /* far_out[i] = 1 iff every string of B is at global edit distance >= min_ed from string i of A, i.e.
  * `min([edit_distance(k, x, max_ed=min_ed) for x in cells_bc.keys()]) >= min_ed` of main.py:250,275 for k = A[i]

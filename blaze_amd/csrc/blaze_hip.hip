@@ -813,6 +813,50 @@ int bz_far_from_all(bz_handle h, const char *a_bytes, const int64_t *a_off, int6
     for (int64_t k = 0; k < n_b; ++k)
         if (b_off[k + 1] < b_off[k] || b_off[k + 1] - b_off[k] > BZ_EXT_MAX) return fail(BZ_E_LIMIT, "string %lld of B: length outside 0..%d", (long long)k, BZ_EXT_MAX);
     if (n_a == 0) return BZ_OK;
+    // the real case -- 16-nt ACGT strings on both sides -- takes the bit-parallel kernel
+    auto regular16 = [](const char *bytes, const int64_t *off, int64_t n) {
+        for (int64_t k = 0; k < n; ++k) {
+            if (off[k + 1] - off[k] != bz::kBcLen) return false;
+            for (int i = 0; i < bz::kBcLen; ++i) { const char c = bytes[off[k] + i]; if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return false; }
+        }
+        return true;
+    };
+    if (n_b > 0 && regular16(a_bytes, a_off, n_a) && regular16(b_bytes, b_off, n_b)) {
+        std::vector<uint32_t> ac(n_a), bp(n_b);
+        for (int64_t k = 0; k < n_a; ++k) {
+            uint32_t c = 0;
+            for (int i = 0; i < bz::kBcLen; ++i) c |= (((uint32_t)(unsigned char)a_bytes[a_off[k] + i] >> 1) & 3u) << (2 * i);
+            ac[k] = c;
+        }
+        for (int64_t k = 0; k < n_b; ++k) {
+            uint32_t hi = 0, lo = 0;
+            for (int i = 0; i < bz::kBcLen; ++i) {
+                const uint32_t c = ((uint32_t)(unsigned char)b_bytes[b_off[k] + i] >> 1) & 3u;
+                hi |= ((c >> 1) & 1u) << i; lo |= (c & 1u) << i;
+            }
+            bp[k] = hi | (lo << 16);
+        }
+        uint32_t *d_ac = nullptr, *d_bp = nullptr;
+        uint8_t *d_f = nullptr;
+        int rc2 = BZ_OK;
+        auto step2 = [&](hipError_t e) { if (e != hipSuccess && rc2 == BZ_OK) rc2 = fail(BZ_E_HIP, "%s", hipGetErrorString(e)); };
+        step2(hipMalloc(&d_ac, n_a * sizeof(uint32_t))); step2(hipMalloc(&d_bp, n_b * sizeof(uint32_t))); step2(hipMalloc(&d_f, n_a));
+        hipStream_t st = h->slot[0].stream;
+        if (rc2 == BZ_OK) {
+            step2(hipMemcpyAsync(d_ac, ac.data(), n_a * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            step2(hipMemcpyAsync(d_bp, bp.data(), n_b * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            step2(hipMemsetAsync(d_f, 1, n_a, st));
+        }
+        if (rc2 == BZ_OK) {
+            hipLaunchKernelGGL(bz::k_far_from_all_16, dim3((unsigned)((n_a + 255) / 256), (unsigned)((n_b + bz::kFarChunk - 1) / bz::kFarChunk)), dim3(256), 0, st,
+                               d_ac, (int)n_a, d_bp, (int)n_b, min_ed, d_f);
+            step2(hipGetLastError());
+            step2(hipMemcpyAsync(far_out, d_f, n_a, hipMemcpyDeviceToHost, st));
+            step2(hipStreamSynchronize(st));
+        }
+        hipFree(d_ac); hipFree(d_bp); hipFree(d_f);
+        return rc2;
+    }
     std::vector<int64_t> ao(n_a + 1), bo(n_b + 1);
     for (int64_t k = 0; k <= n_a; ++k) ao[k] = a_off[k] - a_off[0];
     for (int64_t k = 0; k <= n_b; ++k) bo[k] = b_off[k] - b_off[0];

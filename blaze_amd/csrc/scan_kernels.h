@@ -1243,6 +1243,48 @@ __global__ __launch_bounds__(256) void k_far_from_all(const uint8_t *__restrict_
     far[i] = is_far ? 1 : 0;
 }
 
+// The same test for 16-nt ACGT strings on both sides (the real case: 10x barcodes), bit-parallel: lane = A[i] as the
+// TEXT (16 columns as bit-plane masks, as in the scan kernels), each B string the 16-bit PATTERN of Myers' / Hyyro's
+// global edit-distance recurrence (first row D[0][j] = j: the shifted-in horizontal delta is +1), ~17 ops per column.
+// blockIdx.y splits B into chunks so that a block of a few thousand candidates still fills the chip; far[] must be
+// preset to 1 and any lane that meets a close string clears its entry.
+constexpr int kFarChunk = 256;
+__global__ __launch_bounds__(256) void k_far_from_all_16(const uint32_t *__restrict__ a_codes, int n_a,
+                                                        const uint32_t *__restrict__ b_planes, int n_b, int min_ed,
+                                                        uint8_t *__restrict__ far) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_a) return;
+    const uint32_t code = a_codes[i];
+    uint32_t XH[kBcLen], XL[kBcLen];
+#pragma unroll
+    for (int j = 0; j < kBcLen; ++j) {
+        const uint32_t c = (code >> (2 * j)) & 3u;
+        XH[j] = (c & 2u) ? 0u : 0xFFFFFFFFu;
+        XL[j] = (c & 1u) ? 0u : 0xFFFFFFFFu;
+    }
+    const int k0 = blockIdx.y * kFarChunk, k1 = min(n_b, k0 + kFarChunk);
+    for (int k = k0; k < k1; ++k) {
+        const uint32_t p = b_planes[k];                          // wave-uniform
+        const uint32_t bh = p & 0xFFFFu, bl = p >> 16;
+        uint32_t Pv = 0xFFFFu, Mv = 0u;
+        int score = kBcLen;
+#pragma unroll
+        for (int j = 0; j < kBcLen; ++j) {
+            const uint32_t Eq = (bh ^ XH[j]) & (bl ^ XL[j]) & 0xFFFFu;
+            const uint32_t Xv = Eq | Mv;
+            const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            uint32_t Ph = Mv | ~(Xh | Pv);
+            uint32_t Mh = Pv & Xh;
+            score += (int)((Ph >> (kBcLen - 1)) & 1u) - (int)((Mh >> (kBcLen - 1)) & 1u);
+            Ph = (Ph << 1) | 1u;
+            Mh <<= 1;
+            Pv = (Mh | ~(Xv | Ph)) & 0xFFFFu;
+            Mv = Ph & Xv & 0xFFFFu;
+        }
+        if (score < min_ed) { far[i] = 0; return; }
+    }
+}
+
 __global__ void k_pair(const uint8_t *a, int la, const uint8_t *b, int lb, int max_ed, int tie, int global_mode, int32_t *out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (global_mode) { out[0] = dev_edit_distance(a, la, b, lb, max_ed); out[1] = -1; }

@@ -58,3 +58,28 @@ def test_empty_drop_list_stop_rule(engine, oracle):
     got = whitelisting.empty_drop_list(cand, cells, engine)
     assert len(got) == 2001 and got == oracle.empty_drop_list(cand, cells)
     assert whitelisting.empty_drop_list(cand[:100], cells, engine, max_n=10) == oracle.empty_drop_list(cand[:100], cells, max_n=10)
+
+
+def test_far_from_all_16mers_bitparallel_vs_oracle(engine, oracle):
+    """16-nt ACGT strings on both sides take the bit-parallel kernel: candidates a few edit operations away from a cell
+    barcode (cut or padded back to 16 nt), every threshold around the true distances."""
+    rng = np.random.default_rng(12)
+    acgt = "ACGT"
+    cells = list(dict.fromkeys("".join(acgt[i] for i in rng.integers(0, 4, 16)) for _ in range(700)))
+    cand = []
+    for _ in range(5000):
+        s = list(cells[rng.integers(0, len(cells))])
+        for _ in range(int(rng.integers(0, 9))):
+            op, pos = rng.integers(0, 3), int(rng.integers(0, len(s)))
+            if op == 0:
+                s[pos] = acgt[rng.integers(0, 4)]
+            elif op == 1 and len(s) > 1:
+                del s[pos]
+            else:
+                s.insert(pos, acgt[rng.integers(0, 4)])
+        cand.append(("".join(s) + "ACGTACGTACGTACGT")[:16])
+    for min_ed in (1, 2, 4, 5, 6, 9):
+        got = whitelisting.far_from_all(engine, cand, cells, min_ed)
+        ref = oracle.far_from_all(cand, cells, min_ed)
+        assert np.array_equal(got, ref), (min_ed, int((got != ref).sum()))
+        assert 0 < got.sum() < len(cand) or min_ed in (1, 9)

@@ -318,3 +318,25 @@ def test_full_10x_whitelist_stress(engine, oracle):
     assert (hit >= 0).sum() > 2000
     # with 6.8M barcodes many rows have several near matches: ambiguity must show up
     assert ((flags & _lib.BZ_F_AMBIG) != 0).sum() > 0
+
+
+def test_rccl_single_rank_collective(engine, tmp_path, monkeypatch):
+    """The one collective of the path (per-barcode counts + [assigned, total]) through RCCL itself, world size 1:
+    librccl is dlopen'ed, the id goes through the rendezvous file, the all-reduce runs on the device."""
+    from blaze_amd import dist
+    monkeypatch.setenv("BLAZE_AMD_RDZV_DIR", str(tmp_path))
+    rows, wl = _synthetic(3000, 120, seed=17)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    engine.set_whitelist([w.tobytes() for w in wl])
+    engine.counts_reset()
+    hit, *_ = engine.assign(ext, el, bo, bl, 2)
+    comm = dist.RcclComm(engine, 0, 1)
+    try:
+        counts = comm.allreduce_counts_on_device()
+        assert np.array_equal(counts[:120], np.bincount(hit[hit >= 0], minlength=120))
+        assert counts[120] == (hit >= 0).sum() and counts[121] == 3000
+        assert comm.allreduce_max_f64(2.5) == 2.5
+        assert np.array_equal(comm.allreduce_sum_i64(np.arange(100)), np.arange(100))
+        comm.barrier()
+    finally:
+        engine.comm_destroy()

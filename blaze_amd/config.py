@@ -13,4 +13,4 @@ DEFAULT_GRB_OUT_WHITELIST = 'whitelist.csv'
 DEFAULT_GRB_OUT_FASTQ = "matched_reads.fastq.gz"
 
 # device batching (no counterpart in the reference: its unit of work is --batch-size rows per process)
-DEVICE_BATCH_ROWS = 1 << 18
+DEVICE_BATCH_ROWS = 1 << 16       # rows per device submit: small enough that reading, device and writing of successive batches overlap

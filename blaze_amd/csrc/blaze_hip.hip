@@ -972,6 +972,10 @@ int bz_assign_files(bz_handle *engines, int n_engines, const char *const *fastq_
     job.csv = putative_bc_csv; job.out_path = fastq_out;
     job.gz = gz != 0; job.restrand = restrand != 0; job.max_ed = max_ed; job.batch_size = batch_size;
     job.n_threads = n_threads; job.device_batch_rows = std::min<int64_t>(device_batch_rows, (int64_t)1 << 24);
+    if (const char *lv = getenv("BLAZE_AMD_GZ_LEVEL")) {   // the reference's gzip.compress uses level 9; the decompressed stream is the contract
+        const int v = atoi(lv);
+        if (v >= 1 && v <= 9) job.gz_level = v;
+    }
 
     struct Queue {                                   // reader thread -> main thread, depth 2
         std::mutex mu; std::condition_variable cv;
@@ -979,15 +983,25 @@ int bz_assign_files(bz_handle *engines, int n_engines, const char *const *fastq_
         bool done = false, stop = false;
         std::exception_ptr err;
     } Q;
-    std::thread reader;
+    struct WQueue {                                  // main thread -> writer thread, in order, depth 4
+        std::mutex mu; std::condition_variable cv;
+        std::deque<std::vector<std::string>> q;
+        bool done = false, failed = false;
+    } W;
+    std::thread reader, writer;
     std::deque<std::unique_ptr<bzio::Chunk>> inflight;
     FILE *fo = nullptr;
     int64_t demul_tot = 0, reads_tot = 0, n_chunks = 0;
     int rc = BZ_OK;
+    bzio::StageClock clk;                            // 0 reader, 1 wait for reader, 2 parse, 3 submit, 4 wait device, 5 format, 6 hand to writer, 7 write
+    const double t_job = bzio::StageClock::now();
     auto shutdown = [&]() {
         { std::lock_guard<std::mutex> g(Q.mu); Q.stop = true; }
         Q.cv.notify_all();
         if (reader.joinable()) reader.join();
+        { std::lock_guard<std::mutex> g(W.mu); W.done = true; }
+        W.cv.notify_all();
+        if (writer.joinable()) writer.join();
         for (auto &c : inflight) hipStreamSynchronize(engines[c->engine]->slot[c->slot].stream);
         inflight.clear();
         if (fo) { fclose(fo); fo = nullptr; }
@@ -999,7 +1013,9 @@ int bz_assign_files(bz_handle *engines, int n_engines, const char *const *fastq_
             try {
                 bzio::ChunkReader rd(job);
                 for (;;) {
+                    const double t0 = bzio::StageClock::now();
                     auto ch = rd.next();
+                    clk.t[0] += bzio::StageClock::now() - t0;
                     std::unique_lock<std::mutex> lk(Q.mu);
                     if (!ch) break;
                     Q.cv.wait(lk, [&] { return Q.q.size() < 2 || Q.stop; });
@@ -1014,25 +1030,55 @@ int bz_assign_files(bz_handle *engines, int n_engines, const char *const *fastq_
             { std::lock_guard<std::mutex> g(Q.mu); Q.done = true; }
             Q.cv.notify_all();
         });
+        writer = std::thread([&]() {
+            for (;;) {
+                std::vector<std::string> parts;
+                {
+                    std::unique_lock<std::mutex> lk(W.mu);
+                    W.cv.wait(lk, [&] { return !W.q.empty() || W.done; });
+                    if (W.q.empty()) return;
+                    parts = std::move(W.q.front());
+                    W.q.pop_front();
+                }
+                W.cv.notify_all();
+                const double t0 = bzio::StageClock::now();
+                for (const std::string &part : parts)
+                    if (!part.empty() && !W.failed && fwrite(part.data(), 1, part.size(), fo) != part.size()) {
+                        std::lock_guard<std::mutex> g(W.mu);
+                        W.failed = true;
+                    }
+                clk.t[7] += bzio::StageClock::now() - t0;
+            }
+        });
         const bz_handle e0 = engines[0];
         auto finish = [&](std::unique_ptr<bzio::Chunk> ch) {
             const size_t n = ch->reads.size();
             ch->hit.resize(n); ch->ed.resize(n); ch->end_idx.resize(n); ch->flags.resize(n);
+            double t0 = bzio::StageClock::now();
             if (bz_assign_wait(engines[ch->engine], ch->slot, ch->hit.data(), ch->ed.data(), ch->end_idx.data(), ch->flags.data()) != BZ_OK)
                 throw std::runtime_error(g_err);
+            double t1 = bzio::StageClock::now();
+            clk.t[4] += t1 - t0;
             const int nb = (int)ch->batch_start.size() - 1;
             ch->out.resize(nb); ch->demul.assign(nb, 0);
             bzio::Chunk &c = *ch;
             bzio::parallel_for(nb, job.n_threads, [&](int b) { bzio::format_batch(c, b, job, e0->wl_host, e0->wl_off_host); });
-            for (int b = 0; b < nb; ++b) {
-                if (!c.out[b].empty() && fwrite(c.out[b].data(), 1, c.out[b].size(), fo) != c.out[b].size())
-                    throw std::runtime_error(std::string("write error on ") + fastq_out);
-                demul_tot += c.demul[b];
-            }
+            t0 = bzio::StageClock::now();
+            clk.t[5] += t0 - t1;
+            for (int b = 0; b < nb; ++b) demul_tot += c.demul[b];
             reads_tot += (int64_t)n;
+            {
+                std::unique_lock<std::mutex> lk(W.mu);
+                W.cv.wait(lk, [&] { return W.q.size() < 4 || W.failed; });
+                if (W.failed) throw std::runtime_error(std::string("write error on ") + fastq_out);
+                W.q.push_back(std::move(c.out));
+            }
+            W.cv.notify_all();
+            clk.t[6] += bzio::StageClock::now() - t0;
         };
         for (int64_t k = 0;; ++k) {
             std::unique_ptr<bzio::Chunk> ch;
+            double t0 = bzio::StageClock::now();
             {
                 std::unique_lock<std::mutex> lk(Q.mu);
                 Q.cv.wait(lk, [&] { return !Q.q.empty() || Q.done; });
@@ -1042,20 +1088,25 @@ int bz_assign_files(bz_handle *engines, int n_engines, const char *const *fastq_
                 Q.q.pop_front();
             }
             Q.cv.notify_all();
+            double t1 = bzio::StageClock::now();
+            clk.t[1] += t1 - t0;
             const size_t n = ch->reads.size();
             ch->bc.resize(n); ch->umi.resize(n); ch->post.resize(n); ch->rid.resize(n); ch->polyT.resize(n);
             ch->ext.resize(n * bzio::kExtStride); ch->ext_len.resize(n); ch->bc_off.resize(n); ch->bc_len.resize(n);
             bzio::Chunk &c = *ch;
             bzio::parallel_for((int)c.batch_start.size() - 1, job.n_threads, [&](int b) { bzio::parse_batch(c, b); });
+            clk.t[2] += bzio::StageClock::now() - t1;
             if ((int)inflight.size() == 2 * n_engines) {
                 auto old = std::move(inflight.front());
                 inflight.pop_front();
                 finish(std::move(old));
             }
+            t1 = bzio::StageClock::now();
             c.engine = (int)(k % n_engines); c.slot = (int)((k / n_engines) % 2);
             if (bz_assign_submit(engines[c.engine], c.slot, c.ext.data(), bzio::kExtStride, c.ext_len.data(), c.bc_off.data(),
                                  c.bc_len.data(), (int64_t)n, max_ed) != BZ_OK)
                 throw std::runtime_error(g_err);
+            clk.t[3] += bzio::StageClock::now() - t1;
             inflight.push_back(std::move(ch));
             ++n_chunks;
         }
@@ -1064,6 +1115,10 @@ int bz_assign_files(bz_handle *engines, int n_engines, const char *const *fastq_
             inflight.pop_front();
             finish(std::move(old));
         }
+        { std::lock_guard<std::mutex> g(W.mu); W.done = true; }
+        W.cv.notify_all();
+        writer.join();
+        if (W.failed) throw std::runtime_error(std::string("write error on ") + fastq_out);
         if (fclose(fo) != 0) { fo = nullptr; throw std::runtime_error(std::string("write error on ") + fastq_out); }
         fo = nullptr;
     } catch (const bzio::MismatchError &e) {
@@ -1071,6 +1126,11 @@ int bz_assign_files(bz_handle *engines, int n_engines, const char *const *fastq_
     } catch (const std::exception &e) {
         rc = fail(BZ_E_ARG, "%s", e.what());
     }
+    if (getenv("BLAZE_AMD_IO_TIMING"))
+        fprintf(stderr, "[bz_assign_files] %.3f s total | reader thread %.3f | main: wait reader %.3f parse %.3f submit %.3f wait device %.3f "
+                        "format %.3f hand-over %.3f | writer thread %.3f | %lld reads, %lld chunks, %d threads\n",
+                bzio::StageClock::now() - t_job, clk.t[0], clk.t[1], clk.t[2], clk.t[3], clk.t[4], clk.t[5], clk.t[6], clk.t[7],
+                (long long)reads_tot, (long long)n_chunks, n_threads);
     const std::string keep = g_err;
     shutdown();
     g_err = keep;

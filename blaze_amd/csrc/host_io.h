@@ -17,9 +17,14 @@
 // the member boundaries are the reference's (one member per --batch-size reads per input file), the compressed bytes
 // themselves are not reproducible even in the reference (gzip header mtime).
 #pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <exception>
@@ -32,24 +37,84 @@
 
 namespace bzio {
 
-struct Span { uint32_t off = 0, len = 0; };
+struct Span { char *p = nullptr; uint32_t len = 0; };          // bytes live in a file mapping or in the chunk's arena
 
 inline bool py_space(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x1f); }
 
-// ---- sequential line source over a plain or gzip file (zlib's gzread reads both) ------------------------------
-class LineReader {
+// ---- stable storage for lines that have to be copied (gzip input): blocks never move ----------------------------
+class Arena {
    public:
-    explicit LineReader(const std::string &path) : path_(path) {
+    char *alloc(size_t n) {
+        if (n > room_) {
+            const size_t sz = std::max<size_t>(n, (size_t)4 << 20);
+            blocks_.emplace_back(new char[sz]);
+            cur_ = blocks_.back().get(); room_ = sz;
+        }
+        char *p = cur_;
+        cur_ += n; room_ -= n;
+        return p;
+    }
+    void give_back(size_t n) { cur_ -= n; room_ += n; }          // undo the tail of the last alloc
+   private:
+    std::vector<std::unique_ptr<char[]>> blocks_;
+    char *cur_ = nullptr;
+    size_t room_ = 0;
+};
+
+// ---- sequential line sources: next line without its terminator ("\n" or "\r\n"); false at end of file ----------
+class LineSource {
+   public:
+    virtual ~LineSource() {}
+    virtual bool next(Arena &arena, Span &out) = 0;
+};
+
+// plain file: private writable mapping (quoted csv cells are unescaped in place), lines are NOT copied; the mapping
+// lives as long as the source object, which the job keeps until its last chunk is written
+class MmapLines : public LineSource {
+   public:
+    explicit MmapLines(const std::string &path) {
+        fd_ = open(path.c_str(), O_RDONLY);
+        if (fd_ < 0) throw std::runtime_error("cannot open " + path);
+        struct stat st;
+        if (fstat(fd_, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd_); fd_ = -1; throw std::runtime_error("cannot map " + path); }
+        size_ = (size_t)st.st_size;
+        if (size_) {
+            void *m = mmap(nullptr, size_, PROT_READ | PROT_WRITE, MAP_PRIVATE, fd_, 0);
+            if (m == MAP_FAILED) { close(fd_); fd_ = -1; throw std::runtime_error("cannot map " + path); }
+            base_ = (char *)m;
+            madvise(base_, size_, MADV_SEQUENTIAL);
+        }
+    }
+    ~MmapLines() override { if (base_) munmap(base_, size_); if (fd_ >= 0) close(fd_); }
+    bool next(Arena &, Span &out) override {
+        if (pos_ >= size_) return false;
+        char *p = base_ + pos_;
+        char *nl = (char *)memchr(p, '\n', size_ - pos_);
+        size_t len = nl ? (size_t)(nl - p) : size_ - pos_;
+        pos_ += len + (nl ? 1 : 0);
+        if (len && p[len - 1] == '\r') --len;
+        if (len > 0xFFFFFFFFu) throw std::runtime_error("line longer than 4 GiB");
+        out.p = p; out.len = (uint32_t)len;
+        return true;
+    }
+   private:
+    int fd_ = -1;
+    char *base_ = nullptr;
+    size_t size_ = 0, pos_ = 0;
+};
+
+// gzip (or anything zlib's gzread reads): lines are copied into the chunk's arena
+class GzLines : public LineSource {
+   public:
+    explicit GzLines(const std::string &path) : path_(path) {
         f_ = gzopen(path.c_str(), "rb");
         if (!f_) throw std::runtime_error("cannot open " + path);
         gzbuffer(f_, 1 << 20);
         buf_.resize(8 << 20);
     }
-    ~LineReader() { if (f_) gzclose(f_); }
-    LineReader(const LineReader &) = delete;
-    // Next line without its terminator ("\n" or "\r\n") appended to `dst`; false at end of file.
-    bool next(std::vector<char> &dst, Span &out) {
-        out.off = (uint32_t)dst.size();
+    ~GzLines() override { if (f_) gzclose(f_); }
+    bool next(Arena &arena, Span &out) override {
+        tmp_.clear();
         bool any = false;
         for (;;) {
             if (pos_ == end_) {
@@ -63,32 +128,51 @@ class LineReader {
             const char *nl = (const char *)memchr(p, '\n', end_ - pos_);
             any = true;
             if (nl) {
-                dst.insert(dst.end(), p, nl);
+                tmp_.insert(tmp_.end(), p, nl);
                 pos_ = (size_t)(nl - buf_.data()) + 1;
-                if (dst.size() > out.off && dst.back() == '\r') dst.pop_back();
-                out.len = (uint32_t)(dst.size() - out.off);
-                return true;
+                if (!tmp_.empty() && tmp_.back() == '\r') tmp_.pop_back();
+                return emit(arena, out);
             }
-            dst.insert(dst.end(), p, (const char *)buf_.data() + end_);
+            tmp_.insert(tmp_.end(), p, (const char *)buf_.data() + end_);
             pos_ = end_;
         }
         if (!any) return false;
-        out.len = (uint32_t)(dst.size() - out.off);      // last line without a newline
+        return emit(arena, out);                                  // last line without a newline
+    }
+   private:
+    bool emit(Arena &arena, Span &out) {
+        if (tmp_.size() > 0xFFFFFFFFu) throw std::runtime_error("line longer than 4 GiB");
+        out.p = arena.alloc(tmp_.size() + 1);
+        memcpy(out.p, tmp_.data(), tmp_.size());
+        out.len = (uint32_t)tmp_.size();
         return true;
     }
-
-   private:
     std::string path_;
     gzFile f_ = nullptr;
-    std::vector<char> buf_;
+    std::vector<char> buf_, tmp_;
     size_t pos_ = 0, end_ = 0;
     bool eof_ = false;
+};
+
+inline bool ends_with_gz(const std::string &p) { return p.size() >= 3 && p.compare(p.size() - 3, 3, ".gz") == 0; }
+inline std::shared_ptr<LineSource> open_lines(const std::string &path) {      // '.gz' decides, as read_assignment.py:151
+    if (ends_with_gz(path)) return std::make_shared<GzLines>(path);
+    struct stat st;
+    if (stat(path.c_str(), &st) == 0 && !S_ISREG(st.st_mode)) return std::make_shared<GzLines>(path);   // pipes etc.: streamed
+    return std::make_shared<MmapLines>(path);
+}
+
+// seconds spent per stage of a file job (BLAZE_AMD_IO_TIMING=1 prints them)
+struct StageClock {
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 };
 
 // ---- one device batch worth of input ------------------------------------------------------------------------
 struct Read { Span id, seq, qual, csv; };
 struct Chunk {
-    std::vector<char> text;                  // all bytes the spans point into
+    Arena arena;                             // copied lines (gzip input)
+    std::vector<std::shared_ptr<LineSource>> sources;   // keeps the file mappings the spans point into alive
     std::vector<Read> reads;
     std::vector<uint32_t> batch_start;       // reference batches (gzip member / pandas inference units), + end sentinel
     // filled by parse
@@ -129,38 +213,38 @@ inline bool looks_numeric(const char *s, uint32_t n) {  // would pandas parse th
     return true;
 }
 
-// Split one CSV line into up to 7 cells (RFC-4180 quotes as pandas' C parser reads them).  Quoted cells are
-// unescaped into `scratch` (appended to chunk text by the caller's offsets).
+// Split one CSV line into up to 7 cells (RFC-4180 quotes as pandas' C parser reads them); quoted cells are unescaped
+// in place.
 struct Cells { Span c[7]; int n = 0; };
-inline void split_csv(std::vector<char> &text, Span line, Cells &out, std::string &err) {
+inline void split_csv(Span line, Cells &out, std::string &err) {
     out.n = 0;
-    uint32_t i = line.off;
-    const uint32_t end = line.off + line.len;
+    char *i = line.p;
+    char *const end = line.p + line.len;
     for (;;) {
         if (out.n == 7) { err = "putative bc csv: more than 7 cells in a row"; return; }
         Span cell;
-        if (i < end && text[i] == '"') {               // quoted: unescape in place (result is never longer)
-            uint32_t w = i, r = i + 1;
-            cell.off = w;
+        if (i < end && *i == '"') {                     // quoted: unescape in place (result is never longer)
+            char *w = i, *r = i + 1;
+            cell.p = w;
             while (r < end) {
-                if (text[r] == '"') {
-                    if (r + 1 < end && text[r + 1] == '"') { text[w++] = '"'; r += 2; continue; }
+                if (*r == '"') {
+                    if (r + 1 < end && r[1] == '"') { *w++ = '"'; r += 2; continue; }
                     ++r; break;
                 }
-                text[w++] = text[r++];
+                *w++ = *r++;
             }
-            while (r < end && text[r] != ',') text[w++] = text[r++];   // junk after the closing quote is kept, as pandas does
-            cell.len = w - cell.off;
+            while (r < end && *r != ',') *w++ = *r++;   // junk after the closing quote is kept, as pandas does
+            cell.len = (uint32_t)(w - cell.p);
             i = r;
         } else {
-            cell.off = i;
-            while (i < end && text[i] != ',') ++i;
-            cell.len = i - cell.off;
+            cell.p = i;
+            while (i < end && *i != ',') ++i;
+            cell.len = (uint32_t)(i - cell.p);
         }
         out.c[out.n++] = cell;
         if (i >= end) break;
         ++i;                                            // the comma
-        if (i == end) { if (out.n < 7) { Span e; e.off = end; e.len = 0; out.c[out.n++] = e; } break; }
+        if (i == end) { if (out.n < 7) { Span e; e.p = end; e.len = 0; out.c[out.n++] = e; } break; }
     }
 }
 
@@ -200,37 +284,38 @@ void parallel_for(int n_items, int n_threads, F &&fn) {
 // ---- reader: FASTQ records + the same number of csv lines, cut into device batches of whole reference batches --
 class ChunkReader {
    public:
-    explicit ChunkReader(const Job &job) : job_(job), csv_(job.csv) {
-        std::vector<char> tmp; Span s;
-        if (!csv_.next(tmp, s)) throw std::runtime_error("putative bc csv is empty: " + job.csv);   // header (:150 `next(f)`)
+    explicit ChunkReader(const Job &job) : job_(job), csv_(open_lines(job.csv)) {
+        Arena tmp; Span s;
+        if (!csv_->next(tmp, s)) throw std::runtime_error("putative bc csv is empty: " + job.csv);   // header (:150 `next(f)`)
     }
     // Next chunk or nullptr when every FASTQ file is exhausted.
     std::unique_ptr<Chunk> next() {
         auto ch = std::make_unique<Chunk>();
-        ch->text.reserve(64 << 20);
-        while ((int64_t)ch->reads.size() < job_.device_batch_rows && ch->text.size() < ((size_t)1 << 30)) {   // spans are 32-bit
+        ch->sources.push_back(csv_);
+        if (fq_) ch->sources.push_back(fq_);
+        Arena skip;                                                // '+' lines of gzip input: copied, then dropped
+        while ((int64_t)ch->reads.size() < job_.device_batch_rows) {
             if (!fq_) {
                 if (file_idx_ >= job_.fastq_fns.size()) break;
-                fq_ = std::make_unique<LineReader>(job_.fastq_fns[file_idx_++]);
+                fq_ = open_lines(job_.fastq_fns[file_idx_++]);
+                ch->sources.push_back(fq_);
             }
             // one reference batch: up to batch_size reads of THIS file (helper.batch_iterator is per file, :156-158)
             const uint32_t start = (uint32_t)ch->reads.size();
             int got = 0;
             for (; got < job_.batch_size; ++got) {
                 Read r; Span plus;
-                if (!fq_->next(ch->text, r.id)) break;
-                plus_.clear();
-                if (!fq_->next(ch->text, r.seq) || !fq_->next(plus_, plus) || !fq_->next(ch->text, r.qual))     // '+' line skipped (helper.py:299)
+                if (!fq_->next(ch->arena, r.id)) break;
+                if (!fq_->next(ch->arena, r.seq) || !fq_->next(skip, plus) || !fq_->next(ch->arena, r.qual))     // '+' line skipped (helper.py:299)
                     throw std::runtime_error("truncated FASTQ record in " + job_.fastq_fns[file_idx_ - 1]);
                 ch->reads.push_back(r);
             }
             if (got == 0) { fq_.reset(); continue; }
             ch->batch_start.push_back(start);
             for (int k = 0; k < got; ++k)
-                if (!csv_.next(ch->text, ch->reads[start + k].csv))
+                if (!csv_->next(ch->arena, ch->reads[start + k].csv))
                     throw std::runtime_error("putative bc csv has fewer rows than the FASTQ files have reads");   // StopIteration in the reference
             if (got < job_.batch_size) fq_.reset();
-            if (ch->text.size() > (size_t)3 << 30) throw std::runtime_error("one batch of reads exceeds 3 GiB of text: lower --batch-size");
         }
         if (ch->reads.empty()) return nullptr;
         ch->batch_start.push_back((uint32_t)ch->reads.size());
@@ -238,29 +323,28 @@ class ChunkReader {
     }
 
    private:
-    std::vector<char> plus_;
     const Job &job_;
-    LineReader csv_;
-    std::unique_ptr<LineReader> fq_;
+    std::shared_ptr<LineSource> csv_;
+    std::shared_ptr<LineSource> fq_;
     size_t file_idx_ = 0;
 };
 
-inline Span strip(const std::vector<char> &t, Span s) {               // str.strip()
-    while (s.len && py_space((unsigned char)t[s.off])) { ++s.off; --s.len; }
-    while (s.len && py_space((unsigned char)t[s.off + s.len - 1])) --s.len;
+inline Span strip(Span s) {                                           // str.strip()
+    while (s.len && py_space((unsigned char)*s.p)) { ++s.p; --s.len; }
+    while (s.len && py_space((unsigned char)s.p[s.len - 1])) --s.len;
     return s;
 }
 
 // read id: title[1:].split()[0] (helper.py:301) then .split()[0].strip('@') (read_assignment.py:31)
-inline Span fastq_id(const std::vector<char> &t, Span line) {
-    if (line.len) { ++line.off; --line.len; }                         // title[1:]
-    while (line.len && py_space((unsigned char)t[line.off])) { ++line.off; --line.len; }
+inline Span fastq_id(Span line) {
+    if (line.len) { ++line.p; --line.len; }                           // title[1:]
+    while (line.len && py_space((unsigned char)*line.p)) { ++line.p; --line.len; }
     uint32_t n = 0;
-    while (n < line.len && !py_space((unsigned char)t[line.off + n])) ++n;
+    while (n < line.len && !py_space((unsigned char)line.p[n])) ++n;
     if (n == 0) throw std::runtime_error("FASTQ title line without a read id");   // IndexError in the reference
     line.len = n;
-    while (line.len && t[line.off] == '@') { ++line.off; --line.len; }
-    while (line.len && t[line.off + line.len - 1] == '@') --line.len;
+    while (line.len && *line.p == '@') { ++line.p; --line.len; }
+    while (line.len && line.p[line.len - 1] == '@') --line.len;
     return line;
 }
 
@@ -272,31 +356,31 @@ inline void parse_batch(Chunk &ch, int b) {
     for (uint32_t r = lo; r < hi; ++r) {
         Read &rd = ch.reads[r];
         Cells cells;
-        split_csv(ch.text, rd.csv, cells, err);
+        split_csv(rd.csv, cells, err);
         if (!err.empty()) throw std::runtime_error(err);
         Span cell[7];
         for (int k = 0; k < 7; ++k) {
             cell[k] = k < cells.n ? cells.c[k] : Span();
-            if (is_na_token(ch.text.data() + cell[k].off, cell[k].len)) cell[k].len = 0;   // NaN -> fillna('')
+            if (is_na_token(cell[k].p, cell[k].len)) cell[k].len = 0;   // NaN -> fillna('')
         }
         // columns: read_id, putative_bc, putative_bc_min_q, putative_umi, polyT_end, pre_bc_flanking, post_umi_flanking
         ch.rid[r] = cell[0]; ch.bc[r] = cell[1]; ch.umi[r] = cell[3]; ch.post[r] = cell[6];
-        all_numeric_ids = all_numeric_ids && looks_numeric(ch.text.data() + cell[0].off, cell[0].len);
+        all_numeric_ids = all_numeric_ids && looks_numeric(cell[0].p, cell[0].len);
         double pt = std::numeric_limits<double>::quiet_NaN();
         if (cell[4].len) {
             char tmp[64];
             const uint32_t n = std::min<uint32_t>(cell[4].len, 63);
-            memcpy(tmp, ch.text.data() + cell[4].off, n); tmp[n] = 0;
+            memcpy(tmp, cell[4].p, n); tmp[n] = 0;
             char *e = nullptr;
             pt = strtod(tmp, &e);
             if (e != tmp + n || n != cell[4].len) throw std::runtime_error("putative bc csv: polyT_end is not a number: " + std::string(tmp));
         }
         ch.polyT[r] = pt;
         // FASTQ side
-        rd.seq = strip(ch.text, rd.seq);
-        rd.qual = strip(ch.text, rd.qual);
-        rd.id = fastq_id(ch.text, rd.id);
-        if (rd.id.len != cell[0].len || memcmp(ch.text.data() + rd.id.off, ch.text.data() + cell[0].off, rd.id.len) != 0)
+        rd.seq = strip(rd.seq);
+        rd.qual = strip(rd.qual);
+        rd.id = fastq_id(rd.id);
+        if (rd.id.len != cell[0].len || memcmp(rd.id.p, cell[0].p, rd.id.len) != 0)
             throw MismatchError("Different order in putative bc file and input fastq!");
         // ext = pre_bc_flanking[-2:] + putative_bc + putative_umi[:2]   (:70)
         uint8_t *e = ch.ext.data() + (size_t)r * kExtStride;
@@ -306,9 +390,9 @@ inline void parse_batch(Chunk &ch, int b) {
         const uint32_t npre = std::min<uint32_t>(pre.len, 2), numi = std::min<uint32_t>(cell[3].len, 2);
         const uint32_t total = npre + cell[1].len + numi;
         if (total > kExtStride) throw std::runtime_error("putative_bc longer than the device row (28 nt)");
-        memcpy(e, ch.text.data() + pre.off + pre.len - npre, npre);
-        memcpy(e + npre, ch.text.data() + cell[1].off, cell[1].len);
-        memcpy(e + npre + cell[1].len, ch.text.data() + cell[3].off, numi);
+        memcpy(e, pre.p + pre.len - npre, npre);
+        memcpy(e + npre, cell[1].p, cell[1].len);
+        memcpy(e + npre + cell[1].len, cell[3].p, numi);
         ch.ext_len[r] = (uint8_t)total; ch.bc_off[r] = (uint8_t)npre; ch.bc_len[r] = (uint8_t)cell[1].len;
     }
     if (all_numeric_ids && hi > lo)       // pandas would have made read_id a numeric column: `bc.read_id != r.id` (:220)
@@ -355,7 +439,6 @@ inline void format_batch(Chunk &ch, int b, const Job &job, const std::vector<cha
     const uint32_t lo = ch.batch_start[b], hi = ch.batch_start[b + 1];
     std::string text;
     int64_t demul = 0;
-    const char *T = ch.text.data();
     std::string umi;
     for (uint32_t r = lo; r < hi; ++r) {
         if (ch.bc[r].len == 0) continue;                     // blank row: BC_corrected == '' (:61-62)
@@ -363,20 +446,20 @@ inline void format_batch(Chunk &ch, int b, const Job &job, const std::vector<cha
         if (h < 0) continue;                                 // none / ambiguous (:87-88)
         const Read &rd = ch.reads[r];
         const char *bc; uint32_t bcl;
-        umi.assign(T + ch.umi[r].off, ch.umi[r].len);
-        if (ch.flags[r] & 1u) { bc = T + ch.bc[r].off; bcl = ch.bc[r].len; }       // exact shortcut: untouched
+        umi.assign(ch.umi[r].p, ch.umi[r].len);
+        if (ch.flags[r] & 1u) { bc = ch.bc[r].p; bcl = ch.bc[r].len; }       // exact shortcut: untouched
         else {
             bc = wl_bytes.data() + wl_off[h]; bcl = (uint32_t)(wl_off[h + 1] - wl_off[h]);
             const int adj = (int)ch.end_idx[r] - ((int)ch.ext_len[r] - 1 - 2);      // :93
             if (adj > 0) {                                   // umi[adj:] + post[:adj]
                 const uint32_t a = std::min<uint32_t>((uint32_t)adj, (uint32_t)umi.size());
                 umi.erase(0, a);
-                umi.append(T + ch.post[r].off, std::min<uint32_t>((uint32_t)adj, ch.post[r].len));
+                umi.append(ch.post[r].p, std::min<uint32_t>((uint32_t)adj, ch.post[r].len));
             } else if (adj < 0) {                            // putative_bc[adj:] + umi[:adj]
                 const uint32_t k = (uint32_t)(-adj);
                 const Span pb = ch.bc[r];
                 const uint32_t take = std::min(k, pb.len);
-                std::string nu(T + pb.off + pb.len - take, take);
+                std::string nu(pb.p + pb.len - take, take);
                 if (umi.size() > k) nu.append(umi, 0, umi.size() - k);
                 umi.swap(nu);
             }
@@ -390,10 +473,10 @@ inline void format_batch(Chunk &ch, int b, const Job &job, const std::vector<cha
         py_cut(rd.seq.len, pt, s0, sl);
         py_cut(rd.qual.len, pt, q0, ql);
         text.push_back('@'); text.append(bc, bcl); text.push_back('_'); text.append(umi); text.push_back('#');
-        text.append(T + ch.rid[r].off, ch.rid[r].len); text.push_back('_');
+        text.append(ch.rid[r].p, ch.rid[r].len); text.push_back('_');
         if (strand) text.push_back(strand);
         text.append("\tCB:Z:"); text.append(bc, bcl); text.append("\tUB:Z:"); text.append(umi); text.push_back('\n');
-        const char *sq = T + rd.seq.off + s0, *ql_p = T + rd.qual.off + q0;
+        const char *sq = rd.seq.p + s0, *ql_p = rd.qual.p + q0;
         if (job.restrand && strand == '-') {
             const size_t at = text.size();
             text.resize(at + sl);

@@ -125,7 +125,8 @@ struct bz_engine {
     uint8_t *d_wl_bytes = nullptr;
     int64_t *d_wl_off = nullptr;
     unsigned long long *d_counts = nullptr;
-    uint32_t *d_hist_partial = nullptr;   // kHistBlocks x n_wl private histograms (whitelists up to kHistLdsBins), else null
+    uint32_t *d_hist_partial = nullptr;   // per slot kHistBlocks x n_wl private histograms (whitelists up to kHistLdsBins), else null:
+                                          // the two slots' runs overlap on their streams, so each needs its own
     Slot slot[BZ_SLOTS];
     std::vector<char> wl_host;         // host copy of the whitelist (bz_assign_files writes barcodes from it)
     std::vector<int64_t> wl_off_host;
@@ -393,7 +394,7 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
     HIP_TRY(hipMemcpy(h->d_wl_off, off.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&h->d_counts, counts_bytes(n)));
     HIP_TRY(hipMemset(h->d_counts, 0, counts_bytes(n)));
-    if (n > 0 && n <= bz::kHistLdsBins) HIP_TRY(hipMalloc(&h->d_hist_partial, (size_t)bz::kHistBlocks * n * sizeof(uint32_t)));
+    if (n > 0 && n <= bz::kHistLdsBins) HIP_TRY(hipMalloc(&h->d_hist_partial, (size_t)BZ_SLOTS * bz::kHistBlocks * n * sizeof(uint32_t)));
 
     h->wl_host.assign(bytes + (n ? offsets[0] : 0), bytes + (n ? offsets[0] : 0) + total);
     h->wl_off_host = off;
@@ -638,9 +639,10 @@ int bz_assign_run(bz_handle h, int slot, int max_ed) {
     if (prof) HIP_TRY(hipEventRecord(s.ev[3], s.stream));
     if (n) {
         if (h->d_hist_partial) {
+            uint32_t *const partial = h->d_hist_partial + (size_t)slot * bz::kHistBlocks * h->n_wl;
             hipLaunchKernelGGL(bz::k_hist_partial, dim3(bz::kHistBlocks), dim3(bz::kHistThreads), (size_t)(h->n_wl + 1) * sizeof(uint32_t), s.stream,
-                               s.d_hit, n, (int)h->n_wl, h->d_hist_partial, h->d_counts);
-            hipLaunchKernelGGL(bz::k_hist_reduce, dim3(((int)h->n_wl + 255) / 256), dim3(256), 0, s.stream, h->d_hist_partial, (int)h->n_wl, h->d_counts,
+                               s.d_hit, n, (int)h->n_wl, partial, h->d_counts);
+            hipLaunchKernelGGL(bz::k_hist_reduce, dim3(((int)h->n_wl + 255) / 256), dim3(256), 0, s.stream, partial, (int)h->n_wl, h->d_counts,
                                s.d_counters, next_counters, s.h_counters_dev);
         } else {
             hipLaunchKernelGGL(bz::k_histogram, dim3(std::min((n + 255) / 256, 1024)), dim3(256), 0, s.stream, s.d_hit, n, (int)h->n_wl, h->d_counts,

@@ -1542,7 +1542,7 @@ __global__ __launch_bounds__(256) void k_hist_reduce(const uint32_t *__restrict_
     unsigned long long s = 0;
 #pragma unroll
     for (int k = 0; k < kHistBlocks; ++k) s += v[k];
-    if (s) counts[b] += s;
+    if (s) atomicAdd(&counts[b], s);      // the other slot's run may be adding to the same bin on its own stream
 }
 
 __global__ __launch_bounds__(256) void k_histogram(const int32_t *__restrict__ hit, int n, int n_wl,

@@ -258,6 +258,35 @@ def test_counts_histogram(engine, oracle):
     assert c[100] == (hit >= 0).sum() + (hit2 >= 0).sum() and c[101] == 6000
 
 
+def test_counts_histogram_with_both_slots_in_flight(engine):
+    """Double buffering: the two slots' runs overlap on their own streams and add to the same
+    per-barcode counts.  Every run must be counted exactly once (each slot has its own histogram
+    partials, the reduce adds with atomics)."""
+    rows, wl = _synthetic(300_000, 3000, seed=18)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    half = ext.shape[0] // 2
+    engine.set_whitelist_codes16(wl)
+    engine.stage(0, ext[:half], el[:half], bo[:half], bl[:half])
+    engine.stage(1, ext[half:], el[half:], bo[half:], bl[half:])
+    engine.run(0, 2), engine.sync(0)
+    hit_a = engine.fetch(0)[0]
+    engine.run(1, 2), engine.sync(1)
+    hit_b = engine.fetch(1)[0]
+    assert (hit_a >= 0).sum() > 50_000 and (hit_b >= 0).sum() > 50_000
+    engine.counts_reset()
+    reps = 25
+    for _ in range(reps):                       # back to back on both streams, no sync in between
+        engine.run(0, 2)
+        engine.run(1, 2)
+    engine.sync(0), engine.sync(1)
+    c = engine.counts()
+    expect = reps * (np.bincount(hit_a[hit_a >= 0], minlength=3000) + np.bincount(hit_b[hit_b >= 0], minlength=3000))
+    assert np.array_equal(c[:3000], expect)
+    assert c[3000] == expect.sum() and c[3001] == reps * ext.shape[0]
+    for slot, ref in ((0, hit_a), (1, hit_b)):  # and the rows themselves are untouched by the overlap
+        assert np.array_equal(engine.fetch(slot)[0], ref)
+
+
 @pytest.mark.parametrize("scan_mode", **MODES)
 def test_barcode_anywhere_in_the_text(engine, oracle, scan_mode):
     """The seeds' window ranges at their limits: a whitelist barcode with 0-2 random edit operations placed at EVERY

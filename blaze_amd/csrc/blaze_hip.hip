@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <future>
 #include <limits>
 #include <numeric>
 #include <string>
@@ -1137,6 +1138,196 @@ int bz_assign_files(bz_handle *engines, int n_engines, const char *const *fastq_
     shutdown();
     g_err = keep;
     if (out_counts) { out_counts[0] = demul_tot; out_counts[1] = reads_tot; out_counts[2] = n_chunks; out_counts[3] = 0; }
+    return rc;
+}
+
+// ---- stage 1 over files (native host pipeline, host_io.h) ------------------------------------------------------
+int bz_putative_bc_files(bz_handle *engines, int n_engines, const char *const *fastq_fns, int n_fastq, const char *out_csv,
+                         int kit_5prime, int umi_len, int min_q, int batch_size, int64_t device_batch_reads, int n_threads,
+                         int64_t out_counts[8]) {
+    if (!engines || n_engines < 1 || !fastq_fns || n_fastq < 0 || !out_csv) return fail(BZ_E_ARG, "bad file arguments");
+    if (batch_size < 1 || device_batch_reads < 1 || n_threads < 1) return fail(BZ_E_ARG, "batch_size, device_batch_reads and n_threads must be >= 1");
+    if (umi_len < 0 || umi_len > 64) return fail(BZ_E_ARG, "umi_len %d outside 0..64", umi_len);
+    for (int e = 0; e < n_engines; ++e)
+        if (!engines[e]) return fail(BZ_E_ARG, "null engine");
+    bzio::S1Job job;
+    for (int k = 0; k < n_fastq; ++k) job.fastq_fns.emplace_back(fastq_fns[k]);
+    job.out_path = out_csv; job.kit5 = kit_5prime != 0; job.umi_len = umi_len; job.min_q = min_q; job.batch_size = batch_size;
+    job.n_threads = n_threads; job.device_batch_reads = std::min<int64_t>(device_batch_reads, (int64_t)1 << 22);
+
+    struct Queue {                                   // reader thread -> main thread, depth 2
+        std::mutex mu; std::condition_variable cv;
+        std::deque<std::unique_ptr<bzio::S1Chunk>> q;
+        bool done = false, stop = false;
+        std::exception_ptr err;
+    } Q;
+    struct WQueue {                                  // main thread -> writer thread, in order, depth 4
+        std::mutex mu; std::condition_variable cv;
+        std::deque<std::vector<std::string>> q;
+        bool done = false, failed = false;
+    } W;
+    struct Flight { std::unique_ptr<bzio::S1Chunk> ch; std::future<std::string> dev; };
+    std::thread reader, writer;
+    std::deque<Flight> inflight;
+    FILE *fo = nullptr;
+    int64_t totals[5] = {0, 0, 0, 0, 0}, reads_tot = 0, n_chunks = 0;
+    int rc = BZ_OK;
+    bzio::StageClock clk;                            // 0 reader, 1 wait for reader, 2 pack, 4 wait device, 5 format, 6 hand to writer, 7 write
+    const double t_job = bzio::StageClock::now();
+    auto shutdown = [&]() {
+        { std::lock_guard<std::mutex> g(Q.mu); Q.stop = true; }
+        Q.cv.notify_all();
+        if (reader.joinable()) reader.join();
+        { std::lock_guard<std::mutex> g(W.mu); W.done = true; }
+        W.cv.notify_all();
+        if (writer.joinable()) writer.join();
+        for (auto &f : inflight) if (f.dev.valid()) f.dev.wait();
+        inflight.clear();
+        if (fo) { fclose(fo); fo = nullptr; }
+    };
+    try {
+        reader = std::thread([&]() {
+            try {
+                bzio::FastqChunkReader rd(job);
+                for (;;) {
+                    const double t0 = bzio::StageClock::now();
+                    auto ch = rd.next();
+                    clk.t[0] += bzio::StageClock::now() - t0;
+                    std::unique_lock<std::mutex> lk(Q.mu);
+                    if (!ch) break;
+                    Q.cv.wait(lk, [&] { return Q.q.size() < 2 || Q.stop; });
+                    if (Q.stop) return;
+                    Q.q.push_back(std::move(ch));
+                    Q.cv.notify_all();
+                }
+            } catch (...) {
+                std::lock_guard<std::mutex> g(Q.mu);
+                Q.err = std::current_exception();
+            }
+            { std::lock_guard<std::mutex> g(Q.mu); Q.done = true; }
+            Q.cv.notify_all();
+        });
+        writer = std::thread([&]() {
+            for (;;) {
+                std::vector<std::string> parts;
+                {
+                    std::unique_lock<std::mutex> lk(W.mu);
+                    W.cv.wait(lk, [&] { return !W.q.empty() || W.done; });
+                    if (W.q.empty()) return;
+                    parts = std::move(W.q.front());
+                    W.q.pop_front();
+                }
+                W.cv.notify_all();
+                const double t0 = bzio::StageClock::now();
+                for (const std::string &part : parts)
+                    if (!part.empty() && !W.failed && fwrite(part.data(), 1, part.size(), fo) != part.size()) {
+                        std::lock_guard<std::mutex> g(W.mu);
+                        W.failed = true;
+                    }
+                clk.t[7] += bzio::StageClock::now() - t0;
+            }
+        });
+        // the device search of one chunk on its engine, on a thread of its own (the entry point is synchronous)
+        auto launch = [&](bzio::S1Chunk *c) {
+            return std::async(std::launch::async, [c, &job, engines]() -> std::string {
+                const int r = bz_putative_bc(engines[c->engine], c->seq.data(), c->qual.data(), c->off.data(), (int64_t)c->reads.size(),
+                                             job.kit5 ? 1 : 0, job.umi_len, c->code.data(), c->strand.data(), c->start.data(),
+                                             c->minq.data(), c->polyt.data());
+                return r == BZ_OK ? std::string() : (g_err.empty() ? std::string("device search failed") : g_err);
+            });
+        };
+        auto finish = [&](Flight f) {
+            double t0 = bzio::StageClock::now();
+            const std::string err = f.dev.get();
+            if (!err.empty()) throw std::runtime_error(err);
+            double t1 = bzio::StageClock::now();
+            clk.t[4] += t1 - t0;
+            bzio::S1Chunk &c = *f.ch;
+            const int nb = (int)c.batch_start.size() - 1;
+            c.out.resize(nb); c.pass.resize(nb);
+            bzio::parallel_for(nb, job.n_threads, [&](int b) { bzio::s1_format_batch(c, b, job); });
+            t0 = bzio::StageClock::now();
+            clk.t[5] += t0 - t1;
+            for (int b = 0; b < nb; ++b)
+                for (int k = 0; k < 5; ++k) totals[k] += c.pass[b][k];
+            reads_tot += (int64_t)c.reads.size();
+            if (!fo) {                                   // the reference creates the table with its first batch (main.py:361-362)
+                fo = fopen(out_csv, "wb");
+                if (!fo) throw std::runtime_error(std::string("cannot open ") + out_csv + " for writing");
+            }
+            {
+                std::unique_lock<std::mutex> lk(W.mu);
+                W.cv.wait(lk, [&] { return W.q.size() < 4 || W.failed; });
+                if (W.failed) throw std::runtime_error(std::string("write error on ") + out_csv);
+                W.q.push_back(std::move(c.out));
+            }
+            W.cv.notify_all();
+            clk.t[6] += bzio::StageClock::now() - t0;
+        };
+        for (int64_t k = 0;; ++k) {
+            std::unique_ptr<bzio::S1Chunk> ch;
+            double t0 = bzio::StageClock::now();
+            {
+                std::unique_lock<std::mutex> lk(Q.mu);
+                Q.cv.wait(lk, [&] { return !Q.q.empty() || Q.done; });
+                if (Q.err) std::rethrow_exception(Q.err);
+                if (Q.q.empty()) break;
+                ch = std::move(Q.q.front());
+                Q.q.pop_front();
+            }
+            Q.cv.notify_all();
+            double t1 = bzio::StageClock::now();
+            clk.t[1] += t1 - t0;
+            ch->first = k == 0;
+            ch->engine = (int)(k % n_engines);
+            bzio::s1_pack(*ch, job.n_threads);
+            clk.t[2] += bzio::StageClock::now() - t1;
+            // at most one search in flight per engine: wait for the engine's previous chunk, start this one, and only
+            // then format the old one (its csv text is built while the device works on the next chunk)
+            Flight old;
+            const bool have_old = (int)inflight.size() == n_engines;
+            if (have_old) {
+                old = std::move(inflight.front());
+                inflight.pop_front();
+                t1 = bzio::StageClock::now();
+                old.dev.wait();
+                clk.t[4] += bzio::StageClock::now() - t1;
+            }
+            Flight f;
+            f.dev = launch(ch.get());
+            f.ch = std::move(ch);
+            inflight.push_back(std::move(f));
+            ++n_chunks;
+            if (have_old) finish(std::move(old));
+        }
+        while (!inflight.empty()) {
+            Flight old = std::move(inflight.front());
+            inflight.pop_front();
+            finish(std::move(old));
+        }
+        { std::lock_guard<std::mutex> g(W.mu); W.done = true; }
+        W.cv.notify_all();
+        writer.join();
+        if (W.failed) throw std::runtime_error(std::string("write error on ") + out_csv);
+        if (fo && fclose(fo) != 0) { fo = nullptr; throw std::runtime_error(std::string("write error on ") + out_csv); }
+        fo = nullptr;
+    } catch (const std::exception &e) {
+        rc = fail(BZ_E_ARG, "%s", e.what());
+    }
+    if (getenv("BLAZE_AMD_IO_TIMING"))
+        fprintf(stderr, "[bz_putative_bc_files] %.3f s total | reader thread %.3f | main: wait reader %.3f pack %.3f wait device %.3f "
+                        "format %.3f hand-over %.3f | writer thread %.3f | %lld reads, %lld chunks, %d threads\n",
+                bzio::StageClock::now() - t_job, clk.t[0], clk.t[1], clk.t[2], clk.t[4], clk.t[5], clk.t[6], clk.t[7],
+                (long long)reads_tot, (long long)n_chunks, n_threads);
+    const std::string keep = g_err;
+    shutdown();
+    g_err = keep;
+    if (out_counts) {
+        memset(out_counts, 0, 8 * sizeof(int64_t));
+        out_counts[0] = reads_tot;
+        for (int k = 0; k < 5; ++k) out_counts[1 + k] = totals[k];
+        out_counts[6] = n_chunks;
+    }
     return rc;
 }
 

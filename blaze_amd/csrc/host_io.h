@@ -23,6 +23,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -493,6 +494,179 @@ inline void format_batch(Chunk &ch, int b, const Job &job, const std::vector<cha
     ch.demul[b] = demul;
     if (job.gz) gzip_member(text, ch.out[b], job.gz_level);   // one member per batch, also when empty (gzip.compress(b''))
     else ch.out[b].swap(text);
+}
+
+// =================================================================================================================
+// Stage 1 over files: bz_putative_bc_files().  What it replaces (file:line under /root/reference/blaze):
+//   read_batch_generator                     main.py:304-323      batches of --batch-size reads, file by file
+//   the loop over the pool's results         main.py:355-364      pass-code counts + DataFrame.to_csv per batch
+//   get_raw_bc_from_reads' table             main.py:96-105       the seven columns, None for reads without a barcode
+//   Read.raw_bc / putative_UMI / flankings   polyT_adaptor_finder.py:263-342   slices of the strand view
+// The device gives five numbers per read (k_stage1); the cells are slices of the read at those numbers, cut here with
+// Python's slice rules.  `DataFrame.to_csv` is restated for this table: a batch's putative_bc_min_q / polyT_end columns
+// are int64 when every read of the batch has a barcode ("15"), float64 as soon as one has none ("15.0", blanks for the
+// missing), and all blank when none has; cells holding a comma, a quote or a newline are quoted with doubled quotes
+// (csv.QUOTE_MINIMAL); the header goes out with the first batch of the job only.
+struct S1Read { Span id, seq, qual; };
+struct S1Chunk {
+    Arena arena;
+    std::vector<std::shared_ptr<LineSource>> sources;
+    std::vector<S1Read> reads;
+    std::vector<uint32_t> batch_start;       // reference batches + end sentinel
+    std::vector<char> seq, qual;             // packed for the device
+    std::vector<int64_t> off;
+    std::vector<int32_t> code, start, minq, polyt;
+    std::vector<int8_t> strand;
+    std::vector<std::string> out;            // csv text per reference batch
+    std::vector<std::array<int64_t, 5>> pass;   // per batch: reads with pass code 0, 1, 2, 10, 100
+    int engine = 0;
+    bool first = false;                      // first chunk of the job: its first batch carries the header
+};
+
+struct S1Job {
+    std::vector<std::string> fastq_fns;
+    std::string out_path;
+    bool kit5 = false;
+    int umi_len = 12, min_q = 15, batch_size = 1000, n_threads = 8;
+    int64_t device_batch_reads = 1 << 15, device_batch_bytes = (int64_t)192 << 20;
+};
+
+class FastqChunkReader {
+   public:
+    explicit FastqChunkReader(const S1Job &job) : job_(job) {}
+    std::unique_ptr<S1Chunk> next() {
+        auto ch = std::make_unique<S1Chunk>();
+        if (fq_) ch->sources.push_back(fq_);
+        Arena skip;
+        int64_t bytes = 0;
+        while ((int64_t)ch->reads.size() < job_.device_batch_reads && bytes < job_.device_batch_bytes) {
+            if (!fq_) {
+                if (file_idx_ >= job_.fastq_fns.size()) break;
+                fq_ = open_lines(job_.fastq_fns[file_idx_++]);
+                ch->sources.push_back(fq_);
+            }
+            const uint32_t start = (uint32_t)ch->reads.size();
+            int got = 0;
+            for (; got < job_.batch_size; ++got) {
+                S1Read r; Span plus;
+                if (!fq_->next(ch->arena, r.id)) break;
+                if (!fq_->next(ch->arena, r.seq) || !fq_->next(skip, plus) || !fq_->next(ch->arena, r.qual))
+                    throw std::runtime_error("truncated FASTQ record in " + job_.fastq_fns[file_idx_ - 1]);
+                bytes += r.seq.len;
+                ch->reads.push_back(r);
+            }
+            if (got == 0) { fq_.reset(); continue; }
+            ch->batch_start.push_back(start);
+            if (got < job_.batch_size) fq_.reset();
+        }
+        if (ch->reads.empty()) return nullptr;
+        ch->batch_start.push_back((uint32_t)ch->reads.size());
+        return ch;
+    }
+   private:
+    const S1Job &job_;
+    std::shared_ptr<LineSource> fq_;
+    size_t file_idx_ = 0;
+};
+
+// strip the lines, take the ids, lay sequence and quality bytes out back to back for the device
+inline void s1_pack(S1Chunk &ch, int n_threads) {
+    const size_t n = ch.reads.size();
+    ch.off.assign(n + 1, 0);
+    for (size_t r = 0; r < n; ++r) {
+        S1Read &rd = ch.reads[r];
+        rd.seq = strip(rd.seq); rd.qual = strip(rd.qual);
+        if (rd.seq.len != rd.qual.len) throw std::runtime_error("sequence and quality strings differ in length");
+        // id = title[1:].split()[0] (helper.py:301): no '@' stripping here, unlike read_assignment.py:31
+        Span t = rd.id;
+        if (t.len) { ++t.p; --t.len; }
+        while (t.len && py_space((unsigned char)*t.p)) { ++t.p; --t.len; }
+        uint32_t k = 0;
+        while (k < t.len && !py_space((unsigned char)t.p[k])) ++k;
+        if (k == 0) throw std::runtime_error("FASTQ title line without a read id");   // IndexError in the reference
+        t.len = k;
+        rd.id = t;
+        ch.off[r + 1] = ch.off[r] + rd.seq.len;
+    }
+    ch.seq.resize((size_t)ch.off[n] + 1); ch.qual.resize((size_t)ch.off[n] + 1);
+    const int parts = std::max(1, std::min<int>(n_threads, (int)(n / 256) + 1));
+    parallel_for(parts, n_threads, [&](int p) {
+        const size_t lo = n * p / parts, hi = n * (p + 1) / parts;
+        for (size_t r = lo; r < hi; ++r) {
+            memcpy(ch.seq.data() + ch.off[r], ch.reads[r].seq.p, ch.reads[r].seq.len);
+            memcpy(ch.qual.data() + ch.off[r], ch.reads[r].qual.p, ch.reads[r].qual.len);
+        }
+    });
+    ch.code.resize(n); ch.start.resize(n); ch.minq.resize(n); ch.polyt.resize(n); ch.strand.resize(n);
+}
+
+// view[a:b] of a read (Python slice rules; a may be negative, b is never) appended as one csv cell; the view is the
+// read itself on strand '-' and its reverse complement on '+'
+inline void s1_cell(std::string &text, const Span &seq, bool rc, int64_t a, int64_t b) {
+    const int64_t n = seq.len;
+    if (a < 0) a = std::max<int64_t>(0, a + n);
+    a = std::min(a, n); b = std::min(std::max<int64_t>(b, 0), n);
+    if (b <= a) return;
+    const size_t at = text.size();
+    bool special = false;
+    text.resize(at + (size_t)(b - a));
+    for (int64_t i = a; i < b; ++i) {
+        const char c = rc ? comp(seq.p[n - 1 - i]) : seq.p[i];
+        special = special || c == ',' || c == '"' || c == '\n';
+        text[at + (size_t)(i - a)] = c;
+    }
+    if (special) {
+        std::string q = "\"";
+        for (size_t i = at; i < text.size(); ++i) { if (text[i] == '"') q.push_back('"'); q.push_back(text[i]); }
+        q.push_back('"');
+        text.resize(at);
+        text += q;
+    }
+}
+
+inline void s1_format_batch(S1Chunk &ch, int b, const S1Job &job) {
+    const uint32_t lo = ch.batch_start[b], hi = ch.batch_start[b + 1];
+    std::string &text = ch.out[b];
+    text.clear();
+    if (ch.first && b == 0) text = "read_id,putative_bc,putative_bc_min_q,putative_umi,polyT_end,pre_bc_flanking,post_umi_flanking\n";
+    std::array<int64_t, 5> pass = {0, 0, 0, 0, 0};
+    bool any_none = false;
+    for (uint32_t r = lo; r < hi; ++r) {
+        if (ch.code[r] < 0) throw std::runtime_error("min() arg is an empty sequence");   // polyT_adaptor_finder.py:278 raises on this read
+        any_none = any_none || ch.code[r] != 0;
+    }
+    const char *num_tail = any_none ? ".0," : ",";            // float64 column as soon as one cell of the batch is None
+    char num[32];
+    for (uint32_t r = lo; r < hi; ++r) {
+        const S1Read &rd = ch.reads[r];
+        const Span id0 = rd.id;
+        {                                                     // the id is a cell like any other
+            Span whole = id0;
+            s1_cell(text, whole, false, 0, whole.len);
+        }
+        const int code = ch.code[r];
+        if (code != 0) {
+            text += ",,,,,,\n";
+            pass[code == 1 ? 1 : code == 2 ? 2 : 3] += 1;
+            continue;
+        }
+        const bool rc = ch.strand[r] == '+';
+        const int64_t s = ch.start[r], u = job.umi_len;
+        const int mq = ch.minq[r];
+        pass[(mq != 0 && mq < job.min_q) ? 4 : 0] += 1;       // main.py:88-94 (a minimum quality of 0 is falsy there)
+        text.push_back(',');
+        s1_cell(text, rd.seq, rc, s, s + 16);
+        text.push_back(',');
+        snprintf(num, sizeof num, "%d", mq); text += num; text += num_tail;
+        s1_cell(text, rd.seq, rc, s + 16, s + 16 + u);
+        text.push_back(',');
+        snprintf(num, sizeof num, "%d", ch.polyt[r]); text += num; text += num_tail;
+        s1_cell(text, rd.seq, rc, s - 5, s);
+        text.push_back(',');
+        s1_cell(text, rd.seq, rc, s + 16 + u, s + 16 + u + 5);
+        text.push_back('\n');
+    }
+    ch.pass[b] = pass;
 }
 
 }  // namespace bzio

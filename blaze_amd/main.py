@@ -1,0 +1,145 @@
+"""The three BLAZE stages rebatched around the device: drop-in for the body of
+/root/reference/blaze/main.py:332-416 `main`, taking the namespace the reference's own
+`blaze.parser.parse_arg` returns (argument parsing / CLI stay the reference's: out of scope here).
+
+    stage 1  main.py:344-371   FASTQ files -> putative_bc.csv + pass-code counts -> summary.txt
+             host="native": bz_putative_bc_files (C++ reader / device search / pandas-exact CSV writer),
+             host="python": read_batch_generator + putative_bc.get_raw_bc_from_reads + DataFrame.to_csv
+    stage 2  main.py:376-404   high-quality barcode counts (pandas, as the reference) -> whitelisting.get_bc_whitelist
+             (empty-drop test on the device) -> whitelist.csv, emtpy_bc_list.csv
+    stage 3  main.py:410-416   read_assignment.assign_read -> demultiplexed FASTQ, two summary lines
+
+Files written, their names and their bytes are the reference's (the .gz output up to the gzip
+container, F9); the knee plot (main.py:286-302, matplotlib) is not drawn.  Every stage needs the
+GPU library: there is no CPU search / scoring path behind these functions.
+"""
+from __future__ import annotations
+
+import gzip
+import logging
+import os
+from collections import Counter, defaultdict
+
+import pandas as pd
+
+from . import helper
+from . import putative_bc, read_assignment, whitelisting
+
+logger = logging.getLogger(__name__)
+logger.setLevel(logging.DEBUG)
+
+
+def read_batch_generator(fastq_fns, batch_size):
+    """Batches of reads, file by file (a batch never spans two files): main.py:304-323."""
+    for fn in fastq_fns:
+        opener = gzip.open(fn, "rt") if str(fn).endswith('.gz') else open(fn, "r")
+        with opener as handle:
+            yield from helper.batch_iterator(helper.fastq_parser(handle), batch_size=batch_size)
+
+
+def add_summary(content, args, write_mode='w'):
+    with open(args.summary_fn, write_mode) as f:
+        f.write(content)
+    if not args.minimal_stdout:
+        print(content)
+
+
+def bc_search_qc_report(pass_count, args):
+    """Text of main.py:114-149 (the reference's dedent leaves its 8-space indentation in place)."""
+    total = sum(pass_count.values())
+    found = pass_count[0] + pass_count[100]
+    pad = ' ' * 8
+
+    def pct(x):
+        return f"{x / total * 100:.2f}% of all reads"
+    lines = [
+        '', '',
+        '----------------------stats of the putative barcodes--------------------------', '',
+        pad + 'Total number of reads: ',
+        pad + f'    {total:,}',
+        pad + 'Reads with unambiguous polyT and adapter positions found:            ',
+        pad + f'    {found:,} ({pct(found)})',
+        pad + f'    {pass_count[0]:,} in which all bases in the putative BC have Q>={args.minQ}',
+        pad + 'Failed Reads: ',
+        pad + '    no polyT and adapter positions found: ',
+        pad + f'        {pass_count[1]:,} ({pct(pass_count[1])})',
+        pad + '    polyT and adapter positions found in both end (fail to determine strand): ',
+        pad + f'        {pass_count[2]:,} ({pct(pass_count[2])})',
+        pad + '    multiple polyT and adapter found in one end',
+        pad + f'        {pass_count[10]:,} ({pct(pass_count[10])})',
+        pad + '-------------------------------------------------------------------------------', '', '',
+    ]
+    return '\n'.join(lines)
+
+
+def _engines(devices):
+    return [read_assignment.get_engine(d) for d in read_assignment._device_ids(devices)]
+
+
+def search_putative_bc(args, devices=None, host="native"):
+    """Stage 1 over files: writes args.out_raw_bc_fn, returns {pass code: reads} (main.py:344-364)."""
+    counts = defaultdict(int)
+    if host == "native":
+        threads = max(1, min(int(args.threads or 1), os.cpu_count() or 1, 64))
+        for k, v in putative_bc.putative_bc_files(_engines(devices), args.fastq_fns, args.out_raw_bc_fn, kit=args.kit_version,
+                                                  umi_len=args.umi_len, min_q=args.minQ, batch_size=args.batch_size,
+                                                  n_threads=threads).items():
+            counts[k] += v
+        return counts
+    eng = _engines(devices)[0]
+    for idx, batch in enumerate(read_batch_generator(args.fastq_fns, batch_size=args.batch_size)):
+        count_pass, rst_df = putative_bc.get_raw_bc_from_reads(batch, min_q=args.minQ, kit=args.kit_version,
+                                                               engine=eng, umi_len=args.umi_len)
+        for k, v in count_pass.items():
+            counts[k] += v
+        if idx == 0:
+            rst_df.to_csv(args.out_raw_bc_fn, index=False)
+        else:
+            rst_df.to_csv(args.out_raw_bc_fn, mode='a', index=False, header=False)
+    return counts
+
+
+def count_high_quality_bc(args):
+    """main.py:378-382: counts of putative barcodes whose minimum base quality reaches minQ, in the
+    reference's own insertion order (it decides the order of whitelist.csv and of the empty-drop candidates)."""
+    raw_bc_count = Counter()
+    for df in pd.read_csv(args.out_raw_bc_fn, chunksize=1_000_000):
+        raw_bc_count += Counter(df[df.putative_bc_min_q >= args.minQ].putative_bc.value_counts().to_dict())
+    return raw_bc_count
+
+
+def main(args, devices=None, host="native"):
+    """Run the stages `args.do_bc_search / do_whitelisting / do_demultiplexing` select.  `args` is the namespace
+    of blaze.parser.parse_arg (fastq_fns, out_raw_bc_fn, out_whitelist_fn, out_emptydrop_fn, summary_fn, output_fastq,
+    kit_version, umi_len, minQ, batch_size, threads, expect_cells / count_threshold / force_cells, ...)."""
+    if args is None or isinstance(args, str):
+        raise TypeError("blaze_amd.main.main takes the namespace returned by blaze.parser.parse_arg(arg_string)")
+    if args.do_bc_search:
+        logger.info(f'Getting putative barcodes from {len(args.fastq_fns)} FASTQ files...')
+        raw_bc_pass_count = search_putative_bc(args, devices, host)
+        helper.green_msg(f'Putative barcode table saved in {args.out_raw_bc_fn}', printit=True)
+        add_summary(bc_search_qc_report(raw_bc_pass_count, args), args=args, write_mode='w')
+
+    if args.do_whitelisting:
+        raw_bc_count = count_high_quality_bc(args)
+        try:
+            bc_whitelist, ept_bc = whitelisting.get_bc_whitelist(raw_bc_count, args=args, engine=_engines(devices)[0])
+            with open(args.out_whitelist_fn, 'w') as f:
+                for k in bc_whitelist.keys():
+                    f.write(k + '\n')
+            with open(args.out_emptydrop_fn, 'w') as f:
+                for k in ept_bc:
+                    f.write(k + '\n')
+                helper.green_msg(f'Empty droplet barcode list saved as `{args.out_emptydrop_fn}`.', printit=True)
+            add_summary(f'\nIdentified # of cells: {len(bc_whitelist)}\n', args, write_mode='a')
+        except Exception as e:            # noqa: BLE001  (the reference logs and carries on, main.py:398-402)
+            logger.exception(e)
+            helper.err_msg("Error: Failed to get whitelist. Please check the input files and settings.", printit=True)
+        else:
+            helper.green_msg(f'Whitelist saved as `{args.out_whitelist_fn}`!', printit=True)
+
+    if args.do_demultiplexing:
+        logger.info("Assigning reads to whitelist.\n")
+        demul_count_tot, count_tot = read_assignment.assign_read(args=args, devices=devices, host=host)
+        add_summary(f'\nTotal reads: {count_tot}'
+                    f'\nTotal reads in cells: {demul_count_tot} ({demul_count_tot / count_tot * 100:.2f}%)', args, write_mode='a')

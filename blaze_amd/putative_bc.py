@@ -82,3 +82,28 @@ def get_raw_bc_from_reads(reads, min_q=0, kit=None, engine=None, **kwargs):
     rst_df = pd.DataFrame({'read_id': read_ids, 'putative_bc': bcs, 'putative_bc_min_q': min_qs, 'putative_umi': umis,
                            'polyT_end': trims, 'pre_bc_flanking': pres, 'post_umi_flanking': posts})
     return Counter(raw_bc_pass), rst_df
+
+
+STAGE1_DEVICE_BATCH_READS = 1 << 15       # reads per device submit of the native file pipeline
+
+
+def putative_bc_files(engines, fastq_fns, out_csv, kit, umi_len, min_q=15, batch_size=1000, n_threads=8,
+                      device_batch_reads=STAGE1_DEVICE_BATCH_READS):
+    """Stage 1 over files in C++ (bz_putative_bc_files, blaze_amd/csrc/host_io.h): the loop of main.py:344-364.
+    Writes `out_csv` with the bytes the reference's per-batch `DataFrame.to_csv` calls produce and returns
+    {pass code: reads} (raw_bc_pass_count, main.py:355-360; only codes that occurred)."""
+    import ctypes
+    import os
+    L = _lib.load()
+    handles = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
+    fns = (ctypes.c_char_p * len(fastq_fns))(*[os.fsencode(str(f)) for f in fastq_fns])
+    counts = (ctypes.c_int64 * 8)()
+    rc = L.bz_putative_bc_files(handles, len(engines), fns, len(fastq_fns), os.fsencode(str(out_csv)),
+                                0 if kit in KITS_3P else 1, int(umi_len), int(min_q), int(batch_size), int(device_batch_reads),
+                                int(n_threads), counts)
+    if rc < 0:
+        msg = (L.bz_last_error() or b'').decode(errors='replace')
+        if msg.startswith("min() arg is an empty sequence"):        # what the reference raises on such a read (:278)
+            raise ValueError(msg)
+    _lib.check(rc)
+    return {code: int(counts[1 + k]) for k, code in enumerate((0, 1, 2, 10, 100)) if counts[1 + k]}

@@ -161,6 +161,21 @@ int bz_assign_files(bz_handle *engines, int n_engines, const char *const *fastq_
                     const char *putative_bc_csv, const char *fastq_out, int gz, int restrand, int max_ed,
                     int batch_size, int64_t device_batch_rows, int n_threads, int64_t out_counts[4]);
 
+/* ---- whole stage 1 over files ----------------------------------------------------------------------- */
+/* Native host pipeline = the stage-1 loop of main.py:344-364 with its generator (read_batch_generator,
+ * main.py:304-323; helper.py:275-301) and the table of get_raw_bc_from_reads (main.py:96-105): FASTQ(.gz)
+ * files -> device batches of whole `batch_size`-read reference batches through bz_putative_bc (one search in
+ * flight per engine, round robin, drained in order) -> putative_bc.csv, byte for byte what the reference's
+ * `DataFrame.to_csv` calls write (int / float / blank number cells per reference batch, csv quoting).
+ * `min_q` is --minQ (it only decides the low-quality tag 100 of main.py:91-92), `device_batch_reads` the reads
+ * per device submit, `n_threads` the host threads for packing / formatting.
+ * out_counts: [0] reads seen, [1..5] reads with pass code 0 / 1 / 2 / 10 / 100 (raw_bc_pass_count of
+ * main.py:355-360), [6] device batches.  A read whose barcode slice is empty makes the reference raise
+ * (polyT_adaptor_finder.py:278): BZ_E_ARG with that message.  No file is created when there are no reads. */
+int bz_putative_bc_files(bz_handle *engines, int n_engines, const char *const *fastq_fns, int n_fastq, const char *out_csv,
+                         int kit_5prime, int umi_len, int min_q, int batch_size, int64_t device_batch_reads, int n_threads,
+                         int64_t out_counts[8]);
+
 /* ---- per-barcode counts + the one collective -------------------------------------------- */
 /* Device-resident int64 histogram counts[0..n_wl) of assigned rows per barcode, followed by
  * counts[n_wl] = rows assigned, counts[n_wl+1] = rows seen (the two scalars the reference sums

@@ -11,7 +11,6 @@
 
 #include <algorithm>
 #include <cmath>
-#include <future>
 #include <limits>
 #include <numeric>
 #include <string>
@@ -98,6 +97,16 @@ struct Slot {
     bool timed = false;
 };
 
+// stage 1: one staging set per slot (pinned host + device), grow-only; the file pipeline packs reads straight into
+// the pinned buffers and double-buffers over the two slots' streams
+struct S1Buf {
+    uint8_t *h_seq = nullptr, *h_qual = nullptr, *d_seq = nullptr, *d_qual = nullptr;
+    int64_t *h_off = nullptr, *d_off = nullptr;
+    int32_t *h_i32 = nullptr, *d_i32 = nullptr;     // pass_code, raw_bc_start, min_q, polyT_end: 4 x cap_reads
+    int8_t *h_strand = nullptr, *d_strand = nullptr;
+    int64_t cap_bytes = 0, cap_reads = 0, n = 0;
+};
+
 }  // namespace
 
 struct bz_engine {
@@ -129,6 +138,7 @@ struct bz_engine {
     uint32_t *d_hist_partial = nullptr;   // per slot kHistBlocks x n_wl private histograms (whitelists up to kHistLdsBins), else null:
                                           // the two slots' runs overlap on their streams, so each needs its own
     Slot slot[BZ_SLOTS];
+    S1Buf s1[BZ_SLOTS];
     std::vector<char> wl_host;         // host copy of the whitelist (bz_assign_files writes barcodes from it)
     std::vector<int64_t> wl_off_host;
     // single-pair scratch
@@ -177,6 +187,49 @@ void free_slot(Slot &s) {
     s.d_ed = s.d_end = nullptr;
     s.h_in = s.h_out = nullptr;
     s.cap = 0; s.cap_stride = 0;
+}
+
+void s1_free(S1Buf &b) {
+    hipHostFree(b.h_seq); hipHostFree(b.h_qual); hipHostFree(b.h_off); hipHostFree(b.h_i32); hipHostFree(b.h_strand);
+    hipFree(b.d_seq); hipFree(b.d_qual); hipFree(b.d_off); hipFree(b.d_i32); hipFree(b.d_strand);
+    b = S1Buf();
+}
+
+int s1_ensure(S1Buf &b, hipStream_t st, int64_t bytes, int64_t reads) {
+    if (bytes <= b.cap_bytes && reads <= b.cap_reads) return BZ_OK;
+    HIP_TRY(hipStreamSynchronize(st));
+    const int64_t cb = std::max<int64_t>({bytes + bytes / 4, b.cap_bytes, (int64_t)1 << 20});
+    const int64_t cr = std::max<int64_t>({reads + reads / 4, b.cap_reads, (int64_t)1024});
+    s1_free(b);
+    HIP_TRY(hipHostMalloc(&b.h_seq, (size_t)cb, hipHostMallocDefault)); HIP_TRY(hipHostMalloc(&b.h_qual, (size_t)cb, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&b.h_off, (size_t)(cr + 1) * sizeof(int64_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&b.h_i32, (size_t)cr * 4 * sizeof(int32_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&b.h_strand, (size_t)cr, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&b.d_seq, (size_t)cb)); HIP_TRY(hipMalloc(&b.d_qual, (size_t)cb));
+    HIP_TRY(hipMalloc(&b.d_off, (size_t)(cr + 1) * sizeof(int64_t)));
+    HIP_TRY(hipMalloc(&b.d_i32, (size_t)cr * 4 * sizeof(int32_t))); HIP_TRY(hipMalloc(&b.d_strand, (size_t)cr));
+    b.cap_bytes = cb; b.cap_reads = cr;
+    return BZ_OK;
+}
+
+// reads [0, n) packed in the slot's pinned buffers (h_off[0] == 0) -> copies + k_stage1 + copies back, asynchronous
+int s1_launch(bz_handle h, int slot, int64_t n, int kit5, int umi_len) {
+    S1Buf &b = h->s1[slot];
+    hipStream_t st = h->slot[slot].stream;
+    b.n = n;
+    if (n == 0) return BZ_OK;
+    const int64_t total = b.h_off[n];
+    if (total) {
+        HIP_TRY(hipMemcpyAsync(b.d_seq, b.h_seq, (size_t)total, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b.d_qual, b.h_qual, (size_t)total, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipMemcpyAsync(b.d_off, b.h_off, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(bz::k_stage1, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, b.d_seq, b.d_qual, b.d_off, (int)n, kit5 ? 1 : 0, umi_len,
+                       h->tie_rule, b.d_i32, b.d_strand, b.d_i32 + n, b.d_i32 + 2 * n, b.d_i32 + 3 * n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(b.h_i32, b.d_i32, (size_t)n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(b.h_strand, b.d_strand, (size_t)n, hipMemcpyDeviceToHost, st));
+    return BZ_OK;
 }
 
 // input staging layout: [ext n*stride][len n][off n][bcl n]; output: [hit 4n][ed n][end n][flags n]
@@ -345,6 +398,7 @@ int bz_destroy(bz_handle h) {
     hipDeviceSynchronize();
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     free_whitelist(h);
+    for (S1Buf &b : h->s1) s1_free(b);
     for (Slot &s : h->slot) {
         free_slot(s);
         hipFree(s.d_counters_base); hipHostFree(s.h_counters);
@@ -773,34 +827,20 @@ int bz_putative_bc(bz_handle h, const char *seq, const char *qual, const int64_t
     }
     if (n == 0) return BZ_OK;
     const int64_t total = off[n] - off[0];
-    std::vector<int64_t> o(n + 1);
-    for (int64_t k = 0; k <= n; ++k) o[k] = off[k] - off[0];
-    uint8_t *d_seq = nullptr, *d_qual = nullptr;
-    int64_t *d_off = nullptr;
-    int32_t *d_i32 = nullptr;
-    int8_t *d_strand = nullptr;
-    int rc = BZ_OK;
-    auto step = [&](hipError_t e) { if (e != hipSuccess && rc == BZ_OK) rc = fail(BZ_E_HIP, "%s", hipGetErrorString(e)); };
-    step(hipMalloc(&d_seq, std::max<int64_t>(total, 1))); step(hipMalloc(&d_qual, std::max<int64_t>(total, 1)));
-    step(hipMalloc(&d_off, (n + 1) * sizeof(int64_t))); step(hipMalloc(&d_i32, 4 * n * sizeof(int32_t))); step(hipMalloc(&d_strand, n));
+    S1Buf &b = h->s1[0];
     hipStream_t st = h->slot[0].stream;
-    if (rc == BZ_OK) {
-        if (total) { step(hipMemcpyAsync(d_seq, seq + off[0], total, hipMemcpyHostToDevice, st)); step(hipMemcpyAsync(d_qual, qual + off[0], total, hipMemcpyHostToDevice, st)); }
-        step(hipMemcpyAsync(d_off, o.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
-    }
-    if (rc == BZ_OK) {
-        hipLaunchKernelGGL(bz::k_stage1, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_seq, d_qual, d_off, (int)n, kit_5prime ? 1 : 0, umi_len,
-                           h->tie_rule, d_i32, d_strand, d_i32 + n, d_i32 + 2 * n, d_i32 + 3 * n);
-        step(hipGetLastError());
-        step(hipMemcpyAsync(pass_code, d_i32, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        step(hipMemcpyAsync(raw_bc_start, d_i32 + n, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        step(hipMemcpyAsync(min_q, d_i32 + 2 * n, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        step(hipMemcpyAsync(polyT_end, d_i32 + 3 * n, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        step(hipMemcpyAsync(strand, d_strand, n, hipMemcpyDeviceToHost, st));
-        step(hipStreamSynchronize(st));
-    }
-    hipFree(d_seq); hipFree(d_qual); hipFree(d_off); hipFree(d_i32); hipFree(d_strand);
-    return rc;
+    if (int rc = s1_ensure(b, st, total, n)) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int64_t k = 0; k <= n; ++k) b.h_off[k] = off[k] - off[0];
+    if (total) { memcpy(b.h_seq, seq + off[0], (size_t)total); memcpy(b.h_qual, qual + off[0], (size_t)total); }
+    if (int rc = s1_launch(h, 0, n, kit_5prime, umi_len)) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    memcpy(pass_code, b.h_i32, (size_t)n * sizeof(int32_t));
+    memcpy(raw_bc_start, b.h_i32 + n, (size_t)n * sizeof(int32_t));
+    memcpy(min_q, b.h_i32 + 2 * n, (size_t)n * sizeof(int32_t));
+    memcpy(polyT_end, b.h_i32 + 3 * n, (size_t)n * sizeof(int32_t));
+    memcpy(strand, b.h_strand, (size_t)n);
+    return BZ_OK;
 }
 
 // ---- empty-drop test: which strings of A are far from every string of B (main.py:244-256, :269-281) -------------
@@ -1166,9 +1206,8 @@ int bz_putative_bc_files(bz_handle *engines, int n_engines, const char *const *f
         std::deque<std::vector<std::string>> q;
         bool done = false, failed = false;
     } W;
-    struct Flight { std::unique_ptr<bzio::S1Chunk> ch; std::future<std::string> dev; };
     std::thread reader, writer;
-    std::deque<Flight> inflight;
+    std::deque<std::unique_ptr<bzio::S1Chunk>> inflight;
     FILE *fo = nullptr;
     int64_t totals[5] = {0, 0, 0, 0, 0}, reads_tot = 0, n_chunks = 0;
     int rc = BZ_OK;
@@ -1181,7 +1220,7 @@ int bz_putative_bc_files(bz_handle *engines, int n_engines, const char *const *f
         { std::lock_guard<std::mutex> g(W.mu); W.done = true; }
         W.cv.notify_all();
         if (writer.joinable()) writer.join();
-        for (auto &f : inflight) if (f.dev.valid()) f.dev.wait();
+        for (auto &c : inflight) hipStreamSynchronize(engines[c->engine]->slot[c->slot].stream);
         inflight.clear();
         if (fo) { fclose(fo); fo = nullptr; }
     };
@@ -1227,30 +1266,27 @@ int bz_putative_bc_files(bz_handle *engines, int n_engines, const char *const *f
                 clk.t[7] += bzio::StageClock::now() - t0;
             }
         });
-        // the device search of one chunk on its engine, on a thread of its own (the entry point is synchronous)
-        auto launch = [&](bzio::S1Chunk *c) {
-            return std::async(std::launch::async, [c, &job, engines]() -> std::string {
-                const int r = bz_putative_bc(engines[c->engine], c->seq.data(), c->qual.data(), c->off.data(), (int64_t)c->reads.size(),
-                                             job.kit5 ? 1 : 0, job.umi_len, c->code.data(), c->strand.data(), c->start.data(),
-                                             c->minq.data(), c->polyt.data());
-                return r == BZ_OK ? std::string() : (g_err.empty() ? std::string("device search failed") : g_err);
-            });
-        };
-        auto finish = [&](Flight f) {
+        auto finish = [&](std::unique_ptr<bzio::S1Chunk> ch) {
+            bzio::S1Chunk &c = *ch;
+            bz_handle e = engines[c.engine];
+            S1Buf &b = e->s1[c.slot];
+            const size_t n = c.reads.size();
             double t0 = bzio::StageClock::now();
-            const std::string err = f.dev.get();
-            if (!err.empty()) throw std::runtime_error(err);
+            if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->slot[c.slot].stream) != hipSuccess)
+                throw std::runtime_error("device search failed");
+            c.code.assign(b.h_i32, b.h_i32 + n); c.start.assign(b.h_i32 + n, b.h_i32 + 2 * n);
+            c.minq.assign(b.h_i32 + 2 * n, b.h_i32 + 3 * n); c.polyt.assign(b.h_i32 + 3 * n, b.h_i32 + 4 * n);
+            c.strand.assign(b.h_strand, b.h_strand + n);                // the slot's buffers are free again from here
             double t1 = bzio::StageClock::now();
             clk.t[4] += t1 - t0;
-            bzio::S1Chunk &c = *f.ch;
             const int nb = (int)c.batch_start.size() - 1;
             c.out.resize(nb); c.pass.resize(nb);
-            bzio::parallel_for(nb, job.n_threads, [&](int b) { bzio::s1_format_batch(c, b, job); });
+            bzio::parallel_for(nb, job.n_threads, [&](int bi) { bzio::s1_format_batch(c, bi, job); });
             t0 = bzio::StageClock::now();
             clk.t[5] += t0 - t1;
-            for (int b = 0; b < nb; ++b)
-                for (int k = 0; k < 5; ++k) totals[k] += c.pass[b][k];
-            reads_tot += (int64_t)c.reads.size();
+            for (int bi = 0; bi < nb; ++bi)
+                for (int k = 0; k < 5; ++k) totals[k] += c.pass[bi][k];
+            reads_tot += (int64_t)n;
             if (!fo) {                                   // the reference creates the table with its first batch (main.py:361-362)
                 fo = fopen(out_csv, "wb");
                 if (!fo) throw std::runtime_error(std::string("cannot open ") + out_csv + " for writing");
@@ -1279,29 +1315,28 @@ int bz_putative_bc_files(bz_handle *engines, int n_engines, const char *const *f
             double t1 = bzio::StageClock::now();
             clk.t[1] += t1 - t0;
             ch->first = k == 0;
-            ch->engine = (int)(k % n_engines);
-            bzio::s1_pack(*ch, job.n_threads);
+            ch->engine = (int)(k % n_engines); ch->slot = (int)((k / n_engines) % BZ_SLOTS);
+            bzio::s1_prepare(*ch, job.n_threads);
             clk.t[2] += bzio::StageClock::now() - t1;
-            // at most one search in flight per engine: wait for the engine's previous chunk, start this one, and only
-            // then format the old one (its csv text is built while the device works on the next chunk)
-            Flight old;
-            const bool have_old = (int)inflight.size() == n_engines;
-            if (have_old) {
-                old = std::move(inflight.front());
+            if ((int)inflight.size() == BZ_SLOTS * n_engines) {       // the oldest chunk holds this chunk's staging buffers
+                auto old = std::move(inflight.front());
                 inflight.pop_front();
-                t1 = bzio::StageClock::now();
-                old.dev.wait();
-                clk.t[4] += bzio::StageClock::now() - t1;
+                finish(std::move(old));
             }
-            Flight f;
-            f.dev = launch(ch.get());
-            f.ch = std::move(ch);
-            inflight.push_back(std::move(f));
+            t1 = bzio::StageClock::now();
+            bz_handle e = engines[ch->engine];
+            if (use(e) != BZ_OK) throw std::runtime_error(g_err);
+            const int64_t n = (int64_t)ch->reads.size();
+            S1Buf &b = e->s1[ch->slot];
+            if (s1_ensure(b, e->slot[ch->slot].stream, ch->off[n], n) != BZ_OK) throw std::runtime_error(g_err);
+            bzio::s1_copy(*ch, b.h_seq, b.h_qual, b.h_off, job.n_threads);
+            if (s1_launch(e, ch->slot, n, job.kit5 ? 1 : 0, job.umi_len) != BZ_OK) throw std::runtime_error(g_err);
+            clk.t[3] += bzio::StageClock::now() - t1;
+            inflight.push_back(std::move(ch));
             ++n_chunks;
-            if (have_old) finish(std::move(old));
         }
         while (!inflight.empty()) {
-            Flight old = std::move(inflight.front());
+            auto old = std::move(inflight.front());
             inflight.pop_front();
             finish(std::move(old));
         }
@@ -1315,9 +1350,9 @@ int bz_putative_bc_files(bz_handle *engines, int n_engines, const char *const *f
         rc = fail(BZ_E_ARG, "%s", e.what());
     }
     if (getenv("BLAZE_AMD_IO_TIMING"))
-        fprintf(stderr, "[bz_putative_bc_files] %.3f s total | reader thread %.3f | main: wait reader %.3f pack %.3f wait device %.3f "
+        fprintf(stderr, "[bz_putative_bc_files] %.3f s total | reader thread %.3f | main: wait reader %.3f prepare %.3f pack+submit %.3f wait device %.3f "
                         "format %.3f hand-over %.3f | writer thread %.3f | %lld reads, %lld chunks, %d threads\n",
-                bzio::StageClock::now() - t_job, clk.t[0], clk.t[1], clk.t[2], clk.t[4], clk.t[5], clk.t[6], clk.t[7],
+                bzio::StageClock::now() - t_job, clk.t[0], clk.t[1], clk.t[2], clk.t[3], clk.t[4], clk.t[5], clk.t[6], clk.t[7],
                 (long long)reads_tot, (long long)n_chunks, n_threads);
     const std::string keep = g_err;
     shutdown();

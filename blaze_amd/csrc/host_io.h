@@ -513,13 +513,12 @@ struct S1Chunk {
     std::vector<std::shared_ptr<LineSource>> sources;
     std::vector<S1Read> reads;
     std::vector<uint32_t> batch_start;       // reference batches + end sentinel
-    std::vector<char> seq, qual;             // packed for the device
-    std::vector<int64_t> off;
+    std::vector<int64_t> off;                // where each read goes in the packed device buffers
     std::vector<int32_t> code, start, minq, polyt;
     std::vector<int8_t> strand;
     std::vector<std::string> out;            // csv text per reference batch
     std::vector<std::array<int64_t, 5>> pass;   // per batch: reads with pass code 0, 1, 2, 10, 100
-    int engine = 0;
+    int engine = 0, slot = 0;
     bool first = false;                      // first chunk of the job: its first batch carries the header
 };
 
@@ -569,35 +568,43 @@ class FastqChunkReader {
     size_t file_idx_ = 0;
 };
 
-// strip the lines, take the ids, lay sequence and quality bytes out back to back for the device
-inline void s1_pack(S1Chunk &ch, int n_threads) {
+// strip the lines, take the ids, compute where each read goes in the packed device buffers
+inline void s1_prepare(S1Chunk &ch, int n_threads) {
     const size_t n = ch.reads.size();
-    ch.off.assign(n + 1, 0);
-    for (size_t r = 0; r < n; ++r) {
-        S1Read &rd = ch.reads[r];
-        rd.seq = strip(rd.seq); rd.qual = strip(rd.qual);
-        if (rd.seq.len != rd.qual.len) throw std::runtime_error("sequence and quality strings differ in length");
-        // id = title[1:].split()[0] (helper.py:301): no '@' stripping here, unlike read_assignment.py:31
-        Span t = rd.id;
-        if (t.len) { ++t.p; --t.len; }
-        while (t.len && py_space((unsigned char)*t.p)) { ++t.p; --t.len; }
-        uint32_t k = 0;
-        while (k < t.len && !py_space((unsigned char)t.p[k])) ++k;
-        if (k == 0) throw std::runtime_error("FASTQ title line without a read id");   // IndexError in the reference
-        t.len = k;
-        rd.id = t;
-        ch.off[r + 1] = ch.off[r] + rd.seq.len;
-    }
-    ch.seq.resize((size_t)ch.off[n] + 1); ch.qual.resize((size_t)ch.off[n] + 1);
-    const int parts = std::max(1, std::min<int>(n_threads, (int)(n / 256) + 1));
+    const int parts = std::max(1, std::min<int>(n_threads, (int)(n / 1024) + 1));
     parallel_for(parts, n_threads, [&](int p) {
         const size_t lo = n * p / parts, hi = n * (p + 1) / parts;
         for (size_t r = lo; r < hi; ++r) {
-            memcpy(ch.seq.data() + ch.off[r], ch.reads[r].seq.p, ch.reads[r].seq.len);
-            memcpy(ch.qual.data() + ch.off[r], ch.reads[r].qual.p, ch.reads[r].qual.len);
+            S1Read &rd = ch.reads[r];
+            rd.seq = strip(rd.seq); rd.qual = strip(rd.qual);
+            if (rd.seq.len != rd.qual.len) throw std::runtime_error("sequence and quality strings differ in length");
+            // id = title[1:].split()[0] (helper.py:301): no '@' stripping here, unlike read_assignment.py:31
+            Span t = rd.id;
+            if (t.len) { ++t.p; --t.len; }
+            while (t.len && py_space((unsigned char)*t.p)) { ++t.p; --t.len; }
+            uint32_t k = 0;
+            while (k < t.len && !py_space((unsigned char)t.p[k])) ++k;
+            if (k == 0) throw std::runtime_error("FASTQ title line without a read id");   // IndexError in the reference
+            t.len = k;
+            rd.id = t;
         }
     });
-    ch.code.resize(n); ch.start.resize(n); ch.minq.resize(n); ch.polyt.resize(n); ch.strand.resize(n);
+    ch.off.assign(n + 1, 0);
+    for (size_t r = 0; r < n; ++r) ch.off[r + 1] = ch.off[r] + ch.reads[r].seq.len;
+}
+
+// lay sequence and quality bytes out back to back in the engine's (pinned) staging buffers
+inline void s1_copy(const S1Chunk &ch, uint8_t *seq, uint8_t *qual, int64_t *off, int n_threads) {
+    const size_t n = ch.reads.size();
+    memcpy(off, ch.off.data(), (n + 1) * sizeof(int64_t));
+    const int parts = std::max(1, std::min<int>(4 * n_threads, (int)(n / 256) + 1));
+    parallel_for(parts, n_threads, [&](int p) {
+        const size_t lo = n * p / parts, hi = n * (p + 1) / parts;
+        for (size_t r = lo; r < hi; ++r) {
+            memcpy(seq + ch.off[r], ch.reads[r].seq.p, ch.reads[r].seq.len);
+            memcpy(qual + ch.off[r], ch.reads[r].qual.p, ch.reads[r].qual.len);
+        }
+    });
 }
 
 // view[a:b] of a read (Python slice rules; a may be negative, b is never) appended as one csv cell; the view is the

@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--cells", type=int, default=5000)
     ap.add_argument("--max-ed", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-two-slots", action="store_true",
+                    help="skip the overlapped two-slot leg (tools/profile.sh: keeps every traced launch solo)")
     a = ap.parse_args()
 
     rank, world, local_rank = dist.env_rank_world()
@@ -213,12 +215,14 @@ def main():
     # ---- the engine's double buffering with resident rows: the same K steps alternating over both slots
     #      (two streams; kernels of consecutive steps overlap).  Reported beside `value`, which stays one slot so
     #      that the per-kernel durations below and in profiles/ describe the launches of the timed region.
-    eng.stage(1, ext, el, bo, bl)
-    eng.run(1, a.max_ed)
-    eng.sync(1)
-    dt2 = plumb.max(timed_steps(a.steps, slots=(0, 1)))
-    two_slots = {"reads_per_s": a.rows * world / (dt2 / a.steps), "ms_per_step": dt2 / a.steps * 1e3,
-                 "note": "same K steps, alternating over the engine's two slots (streams): what bz_assign_files does"}
+    two_slots = None
+    if not a.no_two_slots:
+        eng.stage(1, ext, el, bo, bl)
+        eng.run(1, a.max_ed)
+        eng.sync(1)
+        dt2 = plumb.max(timed_steps(a.steps, slots=(0, 1)))
+        two_slots = {"reads_per_s": a.rows * world / (dt2 / a.steps), "ms_per_step": dt2 / a.steps * 1e3,
+                     "note": "same K steps, alternating over the engine's two slots (streams): what bz_assign_files does"}
 
     reps = max(3, min(a.steps, 10))
     t_short = kernel_avg(reps)                            # same launches as the timed region, timed per kernel

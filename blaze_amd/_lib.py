@@ -23,7 +23,7 @@ EXPORTS = [
     "bz_assign_run", "bz_assign_fetch", "bz_slot_sync", "bz_slot_timing", "bz_sub_edit_distance",
     "bz_edit_distance", "bz_counts_reset", "bz_counts_get", "bz_comm_unique_id", "bz_comm_init",
     "bz_comm_allreduce_counts", "bz_comm_allreduce_f64", "bz_comm_destroy", "bz_valu_peak_probe", "bz_assign_files", "bz_far_from_all", "bz_putative_bc",
-    "bz_putative_bc_files",
+    "bz_putative_bc_files", "bz_assign_files_from", "bz_fastq_count_reads",
 ]
 
 
@@ -75,6 +75,8 @@ def load():
         "bz_putative_bc": ([p, p, p, p, i64, i, i, p, p, p, p, p], i),
         "bz_far_from_all": ([p, p, p, i64, p, p, i64, i, p], i),
         "bz_putative_bc_files": ([ctypes.POINTER(p), i, ctypes.POINTER(cp), i, cp, i, i, i, i, i64, i, ctypes.POINTER(i64)], i),
+        "bz_assign_files_from": ([ctypes.POINTER(p), i, ctypes.POINTER(cp), i, cp, i64, cp, i, i, i, i, i64, i, ctypes.POINTER(i64)], i),
+        "bz_fastq_count_reads": ([cp, ctypes.POINTER(i64)], i),
         "bz_assign_files": ([ctypes.POINTER(p), i, ctypes.POINTER(cp), i, cp, cp, i, i, i, i, i64, i, ctypes.POINTER(i64)], i),
     }
     for name, (args, res) in sig.items():

@@ -1001,9 +1001,27 @@ int bz_comm_destroy(bz_handle h) {
 }
 
 // ---- whole step 3 over files (native host pipeline, host_io.h) ------------------------------------------------
+int bz_fastq_count_reads(const char *path, int64_t *n_reads) {
+    if (!path || !n_reads) return fail(BZ_E_ARG, "bad arguments");
+    try {
+        *n_reads = bzio::count_fastq_reads(path);
+    } catch (const std::exception &e) {
+        return fail(BZ_E_ARG, "%s", e.what());
+    }
+    return BZ_OK;
+}
+
 int bz_assign_files(bz_handle *engines, int n_engines, const char *const *fastq_fns, int n_fastq, const char *putative_bc_csv,
                     const char *fastq_out, int gz, int restrand, int max_ed, int batch_size, int64_t device_batch_rows,
                     int n_threads, int64_t out_counts[4]) {
+    return bz_assign_files_from(engines, n_engines, fastq_fns, n_fastq, putative_bc_csv, 0, fastq_out, gz, restrand, max_ed, batch_size,
+                                device_batch_rows, n_threads, out_counts);
+}
+
+int bz_assign_files_from(bz_handle *engines, int n_engines, const char *const *fastq_fns, int n_fastq, const char *putative_bc_csv,
+                         int64_t csv_skip_rows, const char *fastq_out, int gz, int restrand, int max_ed, int batch_size,
+                         int64_t device_batch_rows, int n_threads, int64_t out_counts[4]) {
+    if (csv_skip_rows < 0) return fail(BZ_E_ARG, "negative csv_skip_rows");
     if (!engines || n_engines < 1 || !fastq_fns || n_fastq < 0 || !putative_bc_csv || !fastq_out) return fail(BZ_E_ARG, "bad file arguments");
     if (batch_size < 1 || device_batch_rows < 1 || n_threads < 1) return fail(BZ_E_ARG, "batch_size, device_batch_rows and n_threads must be >= 1");
     for (int e = 0; e < n_engines; ++e) {
@@ -1015,6 +1033,7 @@ int bz_assign_files(bz_handle *engines, int n_engines, const char *const *fastq_
     job.csv = putative_bc_csv; job.out_path = fastq_out;
     job.gz = gz != 0; job.restrand = restrand != 0; job.max_ed = max_ed; job.batch_size = batch_size;
     job.n_threads = n_threads; job.device_batch_rows = std::min<int64_t>(device_batch_rows, (int64_t)1 << 24);
+    job.csv_skip_rows = csv_skip_rows;
     if (const char *lv = getenv("BLAZE_AMD_GZ_LEVEL")) {   // the reference's gzip.compress uses level 9; the decompressed stream is the contract
         const int v = atoi(lv);
         if (v >= 1 && v <= 9) job.gz_level = v;

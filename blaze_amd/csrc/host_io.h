@@ -163,6 +163,21 @@ inline std::shared_ptr<LineSource> open_lines(const std::string &path) {      //
     return std::make_shared<MmapLines>(path);
 }
 
+// reads in a FASTQ file as helper.fastq_parser would yield them: one per four lines (a trailing partial record counts,
+// the reader raises on it later)
+inline int64_t count_fastq_reads(const std::string &path) {
+    auto src = open_lines(path);
+    int64_t lines = 0;
+    Span s;
+    for (;;) {
+        Arena scratch;
+        bool more = true;
+        for (int k = 0; k < 4096 && (more = src->next(scratch, s)); ++k) ++lines;
+        if (!more) break;
+    }
+    return (lines + 3) / 4;
+}
+
 // seconds spent per stage of a file job (BLAZE_AMD_IO_TIMING=1 prints them)
 struct StageClock {
     double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -255,6 +270,7 @@ struct Job {
     bool gz = false, restrand = true;
     int max_ed = 2, batch_size = 1000, n_threads = 8, gz_level = 9;
     int64_t device_batch_rows = 1 << 16;
+    int64_t csv_skip_rows = 0;               // rows of the table that belong to reads of earlier FASTQ files (another rank's)
 };
 
 struct MismatchError : std::runtime_error { using std::runtime_error::runtime_error; };
@@ -288,6 +304,10 @@ class ChunkReader {
     explicit ChunkReader(const Job &job) : job_(job), csv_(open_lines(job.csv)) {
         Arena tmp; Span s;
         if (!csv_->next(tmp, s)) throw std::runtime_error("putative bc csv is empty: " + job.csv);   // header (:150 `next(f)`)
+        for (int64_t k = 0; k < job.csv_skip_rows; ++k) {
+            Arena skip;                                            // copied lines (gzip input) are dropped at once
+            if (!csv_->next(skip, s)) throw std::runtime_error("putative bc csv has fewer rows than the FASTQ files have reads");
+        }
     }
     // Next chunk or nullptr when every FASTQ file is exhausted.
     std::unique_ptr<Chunk> next() {

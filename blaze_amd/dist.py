@@ -146,3 +146,86 @@ def assign_sharded(ext, ext_len, bc_off, bc_len, max_ed, assign_fn, comm, n_whit
     counts[n_whitelist] = int(ok.sum())
     counts[n_whitelist + 1] = hi - lo
     return lo, hi, res, comm.allreduce_sum_i64(counts)
+
+
+# ---------------------------------------------------------------------------------------------- step 3 over files
+def partition_files(sizes, world: int):
+    """Contiguous runs of the job's FASTQ files, one per rank, balanced by bytes: [(lo, hi)] * world.
+    Contiguous so that concatenating the ranks' outputs in rank order keeps the input order (helper.py:191-205's
+    guarantee); a rank may get no file when there are fewer files than ranks."""
+    n = len(sizes)
+    total = float(sum(sizes)) or 1.0
+    bounds, acc, k = [0], 0.0, 0
+    for r in range(1, world):
+        target = total * r / world
+        while k < n and acc + sizes[k] / 2.0 <= target:
+            acc += sizes[k]
+            k += 1
+        bounds.append(k)
+    bounds.append(n)
+    return [(bounds[r], max(bounds[r], bounds[r + 1])) for r in range(world)]
+
+
+def count_fastq_reads(path) -> int:
+    """Reads in a FASTQ(.gz) file as the reference's parser yields them (native line count / 4)."""
+    import ctypes
+    from . import _lib
+    n = ctypes.c_int64(0)
+    _lib.check(_lib.load().bz_fastq_count_reads(os.fsencode(str(path)), ctypes.byref(n)))
+    return n.value
+
+
+def part_path(fastq_out, rank: int) -> str:
+    """Per-rank piece of the output; keeps the suffix that selects gzip (read_assignment.py:279)."""
+    gz = str(fastq_out).endswith('.gz')
+    stem = str(fastq_out)[:-3] if gz else str(fastq_out)
+    return f"{stem}.part{rank:04d}" + ('.gz' if gz else '')
+
+
+def assign_read_sharded(comm, fastq_fns, fastq_out, putative_bc_csv, whitelsit_csv, max_ed, n_process, batchsize,
+                        restrand=True, device=None, count_reads=count_fastq_reads, run_rank=None):
+    """assign_read (read_assignment.py:253-330) with the FASTQ files sharded over the ranks of `comm`, one process
+    per GPU: rank r takes a contiguous run of files (balanced by bytes), counts the reads of its own files, learns
+    from the other ranks' counts how many rows of putative_bc.csv precede its files, demultiplexes its files into
+    `part_path(fastq_out, r)`, and after a barrier rank 0 concatenates the parts in rank order into `fastq_out`
+    (gzip members concatenate; plain text concatenates: the bytes are those of a single-process run).  The scan
+    uses no collective; the two totals are summed once.  Returns the GLOBAL (reads assigned, reads seen)."""
+    from . import read_assignment as ra
+    fastq_fns = [str(f) for f in fastq_fns]
+    spans = partition_files([os.path.getsize(f) for f in fastq_fns], comm.world)
+    lo, hi = spans[comm.rank]
+    mine = np.zeros(comm.world, dtype=np.int64)
+    mine[comm.rank] = sum(count_reads(f) for f in fastq_fns[lo:hi])
+    per_rank = comm.allreduce_sum_i64(mine)                     # every rank's read count
+    skip = int(per_rank[:comm.rank].sum())
+    part = part_path(fastq_out, comm.rank)
+    if run_rank is None:
+        def run_rank(fns, out, csv_skip_rows):
+            whitelist = []
+            with open(whitelsit_csv, 'r') as f:
+                for line in f:
+                    whitelist.append(line.split('-')[0].strip())
+            ordered = list(set(whitelist))
+            dev = device if device is not None else ra._device_ids(None)[0]
+            eng = ra.get_engine(dev)
+            ra._ensure_whitelist(eng, ordered)
+            threads = max(1, min(int(n_process or 1), os.cpu_count() or 1, 64))
+            return ra._assign_files_native([eng], fns, putative_bc_csv, out, str(out).endswith('.gz'), restrand, max_ed, batchsize,
+                                           ra.DEVICE_BATCH_ROWS, threads, csv_skip_rows=csv_skip_rows)
+    demul, total = run_rank(fastq_fns[lo:hi], part, skip) if hi > lo else (0, 0)
+    if hi <= lo:
+        open(part, 'wb').close()
+    sums = comm.allreduce_sum_i64(np.array([demul, total], dtype=np.int64))      # doubles as the barrier before the merge
+    if comm.rank == 0:
+        with open(fastq_out, 'wb') as out:
+            for r in range(comm.world):
+                p = part_path(fastq_out, r)
+                with open(p, 'rb') as f:
+                    while True:
+                        buf = f.read(1 << 24)
+                        if not buf:
+                            break
+                        out.write(buf)
+                os.remove(p)
+    comm.barrier()
+    return int(sums[0]), int(sums[1])

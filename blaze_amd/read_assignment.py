@@ -241,17 +241,18 @@ def _device_ids(devices):
 
 
 def _assign_files_native(engines, fastq_fns, putative_bc_csv, fastq_out, gz, restrand, max_ed, batchsize,
-                         device_batch_rows, n_threads):
-    """bz_assign_files: the C++ host pipeline (blaze_amd/csrc/host_io.h) around the same device scan."""
+                         device_batch_rows, n_threads, csv_skip_rows=0):
+    """bz_assign_files(_from): the C++ host pipeline (blaze_amd/csrc/host_io.h) around the same device scan.
+    `csv_skip_rows`: rows of the table that belong to FASTQ files in front of `fastq_fns` (another rank's)."""
     import ctypes
     from . import _lib
     L = _lib.load()
     handles = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
     fns = (ctypes.c_char_p * len(fastq_fns))(*[os.fsencode(str(f)) for f in fastq_fns])
     counts = (ctypes.c_int64 * 4)()
-    rc = L.bz_assign_files(handles, len(engines), fns, len(fastq_fns), os.fsencode(str(putative_bc_csv)),
-                           os.fsencode(str(fastq_out)), int(bool(gz)), int(bool(restrand)), int(max_ed), int(batchsize),
-                           int(device_batch_rows), int(n_threads), counts)
+    rc = L.bz_assign_files_from(handles, len(engines), fns, len(fastq_fns), os.fsencode(str(putative_bc_csv)),
+                                int(csv_skip_rows), os.fsencode(str(fastq_out)), int(bool(gz)), int(bool(restrand)), int(max_ed),
+                                int(batchsize), int(device_batch_rows), int(n_threads), counts)
     if rc == _lib.BZ_E_MISMATCH:                    # the reference's reaction, read_assignment.py:219-223
         helper.err_msg("Different order in putative bc file and input fastq!", printit=True)
         sys.exit()

@@ -161,6 +161,16 @@ int bz_assign_files(bz_handle *engines, int n_engines, const char *const *fastq_
                     const char *putative_bc_csv, const char *fastq_out, int gz, int restrand, int max_ed,
                     int batch_size, int64_t device_batch_rows, int n_threads, int64_t out_counts[4]);
 
+/* The same for a rank that owns a contiguous run of the job's FASTQ files (one process per GPU, reads sharded by
+ * file): `csv_skip_rows` = reads in the files before this rank's, whose rows of the table are skipped after the header.
+ * Concatenating the ranks' outputs in rank order gives bz_assign_files' output over all the files (reference batches
+ * never span files, read_assignment.py:149-158).  blaze_amd.dist.assign_read_sharded drives it. */
+int bz_assign_files_from(bz_handle *engines, int n_engines, const char *const *fastq_fns, int n_fastq,
+                         const char *putative_bc_csv, int64_t csv_skip_rows, const char *fastq_out, int gz, int restrand,
+                         int max_ed, int batch_size, int64_t device_batch_rows, int n_threads, int64_t out_counts[4]);
+/* Reads in one FASTQ(.gz) file as helper.fastq_parser (helper.py:292-301) would yield them (lines / 4); host only. */
+int bz_fastq_count_reads(const char *path, int64_t *n_reads);
+
 /* ---- whole stage 1 over files ----------------------------------------------------------------------- */
 /* Native host pipeline = the stage-1 loop of main.py:344-364 with its generator (read_batch_generator,
  * main.py:304-323; helper.py:275-301) and the table of get_raw_bc_from_reads (main.py:96-105): FASTQ(.gz)

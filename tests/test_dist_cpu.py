@@ -39,6 +39,84 @@ WORKER = textwrap.dedent("""
 """) % ROOT
 
 
+FILE_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np
+    import torch.distributed as td
+    from blaze_amd import dist
+    td.init_process_group("gloo", init_method="env://")
+    comm = dist.TorchComm()
+    d = sys.argv[1]
+    fns = [os.path.join(d, "f%%d.fastq" %% k) for k in range(5)]
+    seen = {}
+    def count(path):                               # stands in for the native line counter (no library call needed, but it works on CPU too)
+        return dist.count_fastq_reads(path)
+    def run_rank(files, out, csv_skip_rows):       # stands in for the device pipeline: records what the rank was asked to do
+        seen["files"], seen["skip"] = [os.path.basename(f) for f in files], csv_skip_rows
+        n = 0
+        with open(out, "w") as o:
+            for f in files:
+                for line in open(f):
+                    if line.startswith("@"):
+                        o.write(line); n += 1
+        return n // 2, n
+    demul, total = dist.assign_read_sharded(comm, fns, os.path.join(d, "out.fastq"), "unused.csv", "unused.txt", 2, 1, 1000,
+                                            count_reads=count, run_rank=run_rank)
+    reads = [3, 1000, 7, 2000, 11]                 # per file (f1 and f3 are the big ones)
+    assert total == sum(reads), total
+    if comm.rank == 0:
+        assert seen["files"] == ["f0.fastq", "f1.fastq", "f2.fastq"] and seen["skip"] == 0, seen
+        titles = open(os.path.join(d, "out.fastq")).read().split()
+        assert titles == ["@f%%d_%%d" %% (k, i) for k in range(5) for i in range(reads[k])]      # input order kept
+        assert not [f for f in os.listdir(d) if ".part" in f]
+    else:
+        assert seen["files"] == ["f3.fastq", "f4.fastq"] and seen["skip"] == 1010, seen
+    print("rank", comm.rank, "ok")
+""") % ROOT
+
+
+def _launch_two(script, *argv):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), *argv], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert f"rank {rank} ok" in out
+
+
+def test_files_sharded_over_two_ranks_gloo(tmp_path):
+    """assign_read_sharded: contiguous file runs per rank, csv rows to skip from the other rank's read count,
+    parts merged in rank order, totals summed (the device pipeline itself is stubbed: no GPU here)."""
+    reads = [3, 1000, 7, 2000, 11]
+    for k, n in enumerate(reads):
+        with open(tmp_path / f"f{k}.fastq", "w") as f:
+            for i in range(n):
+                f.write(f"@f{k}_{i}\nACGT\n+\nIIII\n")
+    script = tmp_path / "file_worker.py"
+    script.write_text(FILE_WORKER)
+    _launch_two(script, str(tmp_path))
+
+
+def test_partition_files():
+    from blaze_amd import dist
+    for sizes, world in (([10, 10, 10, 10], 2), ([1, 100, 1, 100, 1], 2), ([5], 4), ([], 3), ([3, 3, 3, 3, 3, 3, 3, 3, 3], 8),
+                         ([0, 0, 0], 2), ([1000, 1, 1, 1], 3)):
+        spans = dist.partition_files(sizes, world)
+        assert len(spans) == world and spans[0][0] == 0 and spans[-1][1] == len(sizes)
+        for (a, b), (c, d) in zip(spans, spans[1:]):
+            assert a <= b == c <= d                                # contiguous, ordered, nothing dropped
+    assert dist.partition_files([10, 10, 10, 10], 2) == [(0, 2), (2, 4)]
+    assert dist.part_path("x/out.fastq.gz", 3) == "x/out.fastq.part0003.gz" and dist.part_path("o.fq", 0) == "o.fq.part0000"
+
+
 def test_world_size_2_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)

@@ -205,3 +205,54 @@ def test_native_configs3_shape_10nt_umi(tmp_path):
     b = ra.assign_read(fastq_out=str(tmp_path / "p.fastq"), n_process=1, host="python", **kw)
     assert tuple(map(int, a)) == tuple(map(int, b))
     assert (tmp_path / "n.fastq").read_bytes() == (tmp_path / "p.fastq").read_bytes()
+
+
+class _SoloComm:
+    """One rank of a pretend world, driven in sequence on the one GPU of the box: the other ranks' contributions to
+    the two sums are supplied by the test (no data-path collective exists to emulate)."""
+
+    def __init__(self, rank, world, others):
+        self.rank, self.world, self.others, self.calls = rank, world, others, 0
+
+    def allreduce_sum_i64(self, arr):
+        a = np.asarray(arr, dtype=np.int64) + np.asarray(self.others[self.calls], dtype=np.int64)
+        self.calls += 1
+        return a
+
+    def barrier(self):
+        pass
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_file_shards_concatenate_to_the_single_run(tmp_path, gz):
+    """Reads sharded by FILE over ranks (dist.assign_read_sharded -> bz_assign_files_from with the csv rows of the
+    earlier files skipped): the ranks' parts, concatenated in rank order, are the single-process output."""
+    from blaze_amd import dist
+    n = 5000
+    fns, pc, pw, bounds = _make_files(tmp_path, n, 400, seed=91, n_files=4)
+    suffix = ".fastq.gz" if gz else ".fastq"
+    whole = str(tmp_path / ("whole" + suffix))
+    kw = dict(putative_bc_csv=pc, whitelsit_csv=pw, max_ed=2, batchsize=300, restrand=True)
+    demul, total = ra.assign_read(fastq_fns=fns, fastq_out=whole, n_process=4, host="native", **kw)
+    per_file = [dist.count_fastq_reads(f) for f in fns]
+    assert per_file == [hi - lo for lo, hi in zip(bounds[:-1], bounds[1:])]          # incl. the gzipped one
+    world = 3
+    spans = dist.partition_files([os.path.getsize(f) for f in fns], world)
+    per_rank = [sum(per_file[lo:hi]) for lo, hi in spans]
+    out = str(tmp_path / ("sharded" + suffix))
+    parts, sums = [], np.zeros(2, np.int64)
+    for rank in range(1, world):                       # ranks 1.. first: rank 0 merges, so it goes last
+        others = np.array(per_rank); others[rank] = 0
+        comm = _SoloComm(rank, world, [others, np.zeros(2, np.int64)])
+        d, t = dist.assign_read_sharded(comm, fns, out, n_process=4, device=0, **kw)
+        parts.append((d, t))
+        sums += (d, t)
+        assert os.path.exists(dist.part_path(out, rank))
+    others = np.array(per_rank); others[0] = 0
+    comm = _SoloComm(0, world, [others, sums.copy()])
+    d, t = dist.assign_read_sharded(comm, fns, out, n_process=4, device=0, **kw)
+    assert (d, t) == (int(demul), int(total)) and t == n
+    assert _text(out) == _text(whole)
+    if not gz:
+        assert open(out, "rb").read() == open(whole, "rb").read()
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f]

@@ -38,55 +38,155 @@ struct S1View {                                                     // a read as
 // adaptor end positions found on one strand view: n = 0, 1 or 2 (= more than one distinct), first = the value when n == 1
 struct S1Ends { int n = 0, first = -1; __device__ void add(int v) { if (n == 0) { n = 1; first = v; } else if (v != first) n = 2; } };
 
-__device__ inline S1Ends s1_adaptor_ends(const S1View &view, bool kit5, int tie) {
+constexpr int kS1MaxWins = 16;    // search windows per strand view (a new one needs a gap of > 30 columns: at most 6 in 200)
+constexpr int kS1Row = 204 + 2 * kS1MaxWins;   // bytes of LDS per lane: the 200-nt window + its search windows; 59 dwords: an odd number of banks
+
+// sub_edit_distance(text, pattern) for a FIXED pattern of M characters and a text of n > M characters that sits in LDS:
+// the DP column lives in registers (static unroll over the pattern), one LDS byte per text column.  Same recurrence, same
+// end-index tie rule and same cut-off result as dev_sub_edit_distance (which keeps its column in scratch memory: a
+// loop-carried store -> load chain there cost ~12 ms per read before this form).
+template <int M>
+__device__ __forceinline__ int s1_sub_ed_fixed(const uint8_t *text, int n, const uint8_t (&pat)[M], int max_ed, int tie, int &end_idx) {
+    int col[M + 1];
+#pragma unroll
+    for (int i = 0; i <= M; ++i) col[i] = i;
+    int best = M, best_end = -1;
+    for (int j = 1; j <= n; ++j) {
+        const int tc = text[j - 1];
+        int diag = col[0];
+        col[0] = 0;
+#pragma unroll
+        for (int i = 1; i <= M; ++i) {
+            const int left = col[i];
+            int v = diag + (pat[i - 1] != tc);
+            v = min(v, col[i - 1] + 1);
+            v = min(v, left + 1);
+            diag = left;
+            col[i] = v;
+        }
+        const int sc = col[M];
+        if (sc < best || (tie && sc == best)) { best = sc; best_end = j - 1; }
+    }
+    if (best > max_ed) { end_idx = -1; return max_ed + 1; }
+    end_idx = best_end;
+    return best;
+}
+
+// sub_edit_distance(window, pattern) with the reference's role rule: the window is the text only when it is LONGER
+// than the pattern (fast path); otherwise it is the pattern (rare: windows clipped at the read start) and the generic
+// byte-wise DP runs on a copy.
+__device__ __noinline__ int s1_sub_ed_small(const uint8_t *win, int n, const uint8_t *pat, int m, int tie, int *end_idx) {
+    uint8_t w[16], q[16];                                           // out of line: rare, and its scratch arrays stay out of the hot code
+    for (int i = 0; i < 16; ++i) { w[i] = i < n ? win[i] : 0; q[i] = i < m ? pat[i] : 0; }
+    int end;
+    const int ed = dev_sub_edit_distance(w, n, q, m, kS1MaxEd, tie, end);
+    *end_idx = end;
+    return ed;
+}
+
+template <int M>
+__device__ __forceinline__ int s1_sub_ed(const uint8_t *win, int n, const uint8_t (&pat)[M], int tie, int &end_idx) {
+    static_assert(M <= 16, "pattern longer than the small-window buffer");
+    if (n > M) return s1_sub_ed_fixed<M>(win, n, pat, kS1MaxEd, tie, end_idx);
+    int end;
+    const int ed = s1_sub_ed_small(win, n, pat, M, tie, &end);
+    end_idx = end;
+    return ed;
+}
+
+// adaptor ends on one strand view whose first min(len, 200) characters are v[0 .. n) in LDS
+__device__ inline S1Ends s1_adaptor_ends(uint8_t *v, int n, bool kit5, int tie) {
     const uint8_t adpt[10] = {'C', 'T', 'T', 'C', 'C', 'G', 'A', 'T', 'C', 'T'};                         // config.py:12
     const uint8_t tso[13] = {'T', 'T', 'T', 'C', 'T', 'T', 'A', 'T', 'A', 'T', 'G', 'G', 'G'};          // config.py:24
-    uint8_t v[kS1Win];
-    const int n = min(view.len, kS1Win);
-    for (int i = 0; i < n; ++i) v[i] = view.at(i);
     S1Ends ends;
     int end;
     if (kit5) {                                                     // :50-63
-        dev_sub_edit_distance(v, n, tso, 13, kS1MaxEd, tie, end);
+        s1_sub_ed<13>(v, n, tso, tie, end);
         if (end > 0) {
             const int tso_start = max(0, end - 13);
             const int lo = max(0, tso_start - kS1D2), hi = max(0, tso_start - kS1D1);
-            dev_sub_edit_distance(v + lo, hi - lo, adpt, 10, kS1MaxEd, tie, end);
+            s1_sub_ed<10>(v + lo, hi - lo, adpt, tie, end);
             if (end > 0) ends.add(lo + end + 1);
         }
         return ends;
     }
-    // :118-144.  T_prop[i] covers v[i+1 .. i+4] (cumsum differences, helper.py:61-63); positions >= d1 open windows
+    // :118-144.  T_prop[i] covers v[i+1 .. i+4] (cumsum differences, helper.py:61-63); positions >= d1 open windows.
+    // Two phases, so that the lanes of a wave run their DPs together: first every lane lists its (merged) search
+    // windows behind its text in LDS -- at most 6 fit 200 columns --, then the w-th windows of all lanes are searched
+    // in the same pass (with the search inside the position loop a wave ran one DP per DISTINCT window end among its
+    // 64 reads, ~0.7 ms per wave).
+    uint8_t *wins = v + kS1Win + 4;                                  // [2w] = start (clipped at 0), [2w+1] = end
+    int nw = 0;
     bool open = false;
     int ws = 0, we = 0;
+    int run = 0;                                                    // T's in a row ending at v[i+4]
+    for (int k = kS1D1 + 1; k < min(n, kS1D1 + 4); ++k) run = v[k] == 'T' ? run + 1 : 0;
     for (int i = kS1D1; i < n - 4; ++i) {
-        if (!(v[i + 1] == 'T' && v[i + 2] == 'T' && v[i + 3] == 'T' && v[i + 4] == 'T')) continue;
+        run = v[i + 4] == 'T' ? run + 1 : 0;
+        if (run < 4) continue;
         if (!open) { ws = i - kS1D2; we = i - kS1D1; open = true; }
         else if (i - kS1D2 > we) {
-            dev_sub_edit_distance(v + max(ws, 0), we - max(ws, 0), adpt, 10, kS1MaxEd, tie, end);
-            if (end > 0) ends.add(max(ws, 0) + end + 1);
+            wins[2 * nw] = (uint8_t)max(ws, 0); wins[2 * nw + 1] = (uint8_t)we; ++nw;
             ws = i - kS1D2; we = i - kS1D1;
         } else we = i - kS1D1;
     }
-    if (open) {
-        dev_sub_edit_distance(v + max(ws, 0), we - max(ws, 0), adpt, 10, kS1MaxEd, tie, end);
-        if (end > 0) ends.add(max(ws, 0) + end + 1);
+    if (open) { wins[2 * nw] = (uint8_t)max(ws, 0); wins[2 * nw + 1] = (uint8_t)we; ++nw; }
+    for (int w = 0; w < nw; ++w) {
+        const int lo = wins[2 * w], hi = wins[2 * w + 1];
+        s1_sub_ed<10>(v + lo, hi - lo, adpt, tie, end);
+        if (end > 0) ends.add(lo + end + 1);
     }
     return ends;
 }
 
+// 'T' flags of view[base .. base + 40) as a bit mask (positions past the end read as 0), 8 byte loads in flight; out of
+// line: called a few times per read, and inlined thrice it cost the kernel its registers (256 VGPRs + 2.4 KB of spills)
+__device__ __noinline__ uint64_t s1_tbits(const S1View &view, int base) {
+    uint64_t m = 0;
+#pragma unroll 8
+    for (int k = 0; k < 40; ++k) {
+        const int i = base + k;
+        const uint8_t c = view.at(min(max(i, 0), max(view.len - 1, 0)));
+        m |= (uint64_t)((i < view.len) & (c == 'T')) << k;
+    }
+    return m;
+}
+
+// one wave = 64 reads.  Per strand view the wave copies every read's first 200 characters into LDS together (coalesced
+// byte loads, complemented on the way for the reverse view), then each lane searches its own row.
 __global__ __launch_bounds__(64) void k_stage1(const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
                                               const int64_t *__restrict__ off, int n_reads, int kit5, int umi_len, int tie,
                                               int32_t *__restrict__ pass_out, int8_t *__restrict__ strand_out,
                                               int32_t *__restrict__ start_out, int32_t *__restrict__ minq_out,
                                               int32_t *__restrict__ polyt_out) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
-    const uint8_t *s = seq + off[r], *q = qual + off[r];
-    const int len = (int)(off[r + 1] - off[r]);
-    S1View fwd{s, len, false}, rev{s, len, true};
-    const S1Ends em = s1_adaptor_ends(fwd, kit5 != 0, tie);       // strand '-': the read as it is
-    const S1Ends ep = s1_adaptor_ends(rev, kit5 != 0, tie);       // strand '+': reverse complement of the last 200 nt
+    __shared__ uint8_t s_text[64 * kS1Row];
+    const int lane = threadIdx.x;
+    const int r = blockIdx.x * 64 + lane;
+    const bool active = r < n_reads;
+    const long long o = active ? (long long)off[r] : 0;
+    const int len = active ? (int)(off[r + 1] - off[r]) : 0;
+    const uint8_t *s = seq + o, *q = qual + o;
+    S1Ends found[2];                                              // [0] strand '-': the read as it is, [1] strand '+'
+#pragma unroll 1
+    for (int view = 0; view < 2; ++view) {
+        __syncthreads();                                          // the previous view's rows are no longer read
+#pragma unroll 4
+        for (int k = 0; k < 64; ++k) {                            // read k of the wave, all lanes together (4 reads' loads in flight)
+            const long long ok = __shfl(o, k);
+            const int lk = __shfl(len, k);
+            const int nk = min(lk, kS1Win);
+            const uint8_t *sk = seq + ok;
+#pragma unroll
+            for (int c = 0; c < (kS1Win + 63) / 64; ++c) {
+                const int i = c * 64 + lane;
+                if (i < nk) s_text[k * kS1Row + i] = view ? s1_comp(sk[lk - 1 - i]) : sk[i];
+            }
+        }
+        __syncthreads();
+        if (active) found[view] = s1_adaptor_ends(s_text + lane * kS1Row, min(len, kS1Win), kit5 != 0, tie);
+    }
+    if (!active) return;
+    const S1Ends em = found[0], ep = found[1];
     int code = 0;
     const int n_strands = (em.n > 0) + (ep.n > 0);
     if (n_strands == 0) code = 1;
@@ -97,24 +197,32 @@ __global__ __launch_bounds__(64) void k_stage1(const uint8_t *__restrict__ seq, 
         const bool plus = ep.n > 0;
         strand = plus ? '+' : '-';
         start = plus ? ep.first : em.first;
-        const S1View view = plus ? rev : fwd;
+        const S1View view{s, len, plus};
         // :270-278 minimum quality of the 16 barcode bases (the reversed quality string on '+')
         int mq = 1 << 30;
-        for (int i = start; i < min(start + kBcLen, len); ++i) mq = min(mq, (int)(plus ? q[len - 1 - i] : q[i]));
+#pragma unroll
+        for (int k = 0; k < kBcLen; ++k) {
+            const int i = start + k;
+            if (i < len) mq = min(mq, (int)(plus ? q[len - 1 - i] : q[i]));
+        }
         if (mq == 1 << 30) code = kS1PassError;
         else minq = mq - 33;
-        // :344-379
+        // :344-379 on a stream of 'T' flags, 32 positions per refill
         const int umi_end = start + kBcLen + umi_len;
         int p = -1;
-        for (int i = umi_end; i + 4 <= len; ++i)
-            if (view.at(i) == 'T' && view.at(i + 1) == 'T' && view.at(i + 2) == 'T' && view.at(i + 3) == 'T') { p = i; break; }
+        for (int base = umi_end; base + 4 <= len; base += 32) {    // first 'TTTT' at or behind the UMI's end
+            const uint64_t m = s1_tbits(view, base);
+            const uint32_t f = (uint32_t)(m & (m >> 1) & (m >> 2) & (m >> 3));
+            if (f) { p = base + __builtin_ctz(f); break; }
+        }
         if (p < 0) polyt = umi_end;                                 // unsigned on BOTH strands (:368-369)
         else {
+            int base = p;
+            uint64_t m = s1_tbits(view, base);
             while (p < len) {
-                if (view.at(p) == 'T') { ++p; continue; }
-                int t = 0;
-                for (int k = p; k < min(p + 10, len); ++k) t += view.at(k) == 'T';
-                if (t >= 7) ++p; else break;
+                if (p - base > 24) { base = p; m = s1_tbits(view, base); }
+                const uint32_t w = (uint32_t)(m >> (p - base));
+                if ((w & 1u) || __popc(w & 0x3FFu) >= 7) ++p; else break;
             }
             polyt = plus ? -p : p;
         }

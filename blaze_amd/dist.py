@@ -229,3 +229,57 @@ def assign_read_sharded(comm, fastq_fns, fastq_out, putative_bc_csv, whitelsit_c
                 os.remove(p)
     comm.barrier()
     return int(sums[0]), int(sums[1])
+
+
+def make_comm(engine=None):
+    """The communicator of this process: RCCL through the engine when launched with WORLD_SIZE > 1 on GPUs, else local."""
+    rank, world, _ = env_rank_world()
+    if world == 1:
+        return LocalComm()
+    return RcclComm(engine, rank, world)
+
+
+# ---------------------------------------------------------------------------------------------- stage 1 over files
+def _merge_parts(out_path, parts, skip_header_after_first=False):
+    """Concatenate the ranks' parts in rank order into out_path and delete them.  With skip_header_after_first the
+    first line of every non-empty part but the first is dropped (csv parts each start with the header)."""
+    wrote = False
+    with open(out_path, 'wb') as out:
+        for p in parts:
+            if not os.path.exists(p):
+                continue
+            with open(p, 'rb') as f:
+                if skip_header_after_first and wrote:
+                    f.readline()
+                while True:
+                    buf = f.read(1 << 24)
+                    if not buf:
+                        break
+                    out.write(buf)
+                    wrote = True
+            os.remove(p)
+    if not wrote:
+        os.remove(out_path)                     # no reads at all: the reference never creates the table (main.py:361)
+
+
+def putative_bc_files_sharded(comm, fastq_fns, out_csv, kit, umi_len, min_q, batch_size, n_threads, device=None, run_rank=None):
+    """The stage-1 loop (main.py:344-364) with the FASTQ files sharded over the ranks of `comm`, one process per GPU:
+    rank r searches its contiguous run of files into `part_path(out_csv, r)`, the pass-code counts are summed once, and
+    rank 0 concatenates the parts in rank order (one header) into `out_csv`: the bytes of a single-process run, because
+    reference batches never span files (main.py:311-323).  Returns the GLOBAL {pass code: reads}."""
+    from . import putative_bc, read_assignment as ra
+    fastq_fns = [str(f) for f in fastq_fns]
+    lo, hi = partition_files([os.path.getsize(f) for f in fastq_fns], comm.world)[comm.rank]
+    part = part_path(out_csv, comm.rank)
+    if run_rank is None:
+        def run_rank(fns, out):
+            eng = ra.get_engine(device if device is not None else ra._device_ids(None)[0])
+            return putative_bc.putative_bc_files([eng], fns, out, kit=kit, umi_len=umi_len, min_q=min_q, batch_size=batch_size,
+                                                 n_threads=n_threads)
+    counts = run_rank(fastq_fns[lo:hi], part) if hi > lo else {}
+    codes = (0, 1, 2, 10, 100)
+    sums = comm.allreduce_sum_i64(np.array([counts.get(c, 0) for c in codes], dtype=np.int64))   # doubles as the barrier
+    if comm.rank == 0:
+        _merge_parts(out_csv, [part_path(out_csv, r) for r in range(comm.world)], skip_header_after_first=True)
+    comm.barrier()
+    return {c: int(v) for c, v in zip(codes, sums) if v}

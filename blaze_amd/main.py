@@ -76,9 +76,17 @@ def _engines(devices):
     return [read_assignment.get_engine(d) for d in read_assignment._device_ids(devices)]
 
 
-def search_putative_bc(args, devices=None, host="native"):
-    """Stage 1 over files: writes args.out_raw_bc_fn, returns {pass code: reads} (main.py:344-364)."""
+def search_putative_bc(args, devices=None, host="native", comm=None):
+    """Stage 1 over files: writes args.out_raw_bc_fn, returns {pass code: reads} (main.py:344-364).
+    With a multi-rank `comm` the files are sharded over the ranks (dist.putative_bc_files_sharded)."""
     counts = defaultdict(int)
+    if comm is not None and comm.world > 1:
+        from . import dist
+        threads = max(1, min(int(args.threads or 1), os.cpu_count() or 1, 64))
+        counts.update(dist.putative_bc_files_sharded(comm, args.fastq_fns, args.out_raw_bc_fn, args.kit_version, args.umi_len,
+                                                     args.minQ, args.batch_size, threads,
+                                                     device=read_assignment._device_ids(devices)[0]))
+        return counts
     if host == "native":
         threads = max(1, min(int(args.threads or 1), os.cpu_count() or 1, 64))
         for k, v in putative_bc.putative_bc_files(_engines(devices), args.fastq_fns, args.out_raw_bc_fn, kit=args.kit_version,
@@ -108,15 +116,20 @@ def count_high_quality_bc(args):
     return raw_bc_count
 
 
-def main(args, devices=None, host="native"):
+def main(args, devices=None, host="native", comm=None):
     """Run the stages `args.do_bc_search / do_whitelisting / do_demultiplexing` select.  `args` is the namespace
     of blaze.parser.parse_arg (fastq_fns, out_raw_bc_fn, out_whitelist_fn, out_emptydrop_fn, summary_fn, output_fastq,
-    kit_version, umi_len, minQ, batch_size, threads, expect_cells / count_threshold / force_cells, ...)."""
+    kit_version, umi_len, minQ, batch_size, threads, expect_cells / count_threshold / force_cells, ...).
+    One process per GPU (`comm` from dist.make_comm(), world > 1): stages 1 and 3 shard the FASTQ files over the
+    ranks, stage 2 and the summary are rank 0's; the files on disk are those of a single-process run."""
     if args is None or isinstance(args, str):
         raise TypeError("blaze_amd.main.main takes the namespace returned by blaze.parser.parse_arg(arg_string)")
+    multi = comm is not None and comm.world > 1
+    if multi and comm.rank != 0:
+        return _main_worker_rank(args, devices, comm)
     if args.do_bc_search:
         logger.info(f'Getting putative barcodes from {len(args.fastq_fns)} FASTQ files...')
-        raw_bc_pass_count = search_putative_bc(args, devices, host)
+        raw_bc_pass_count = search_putative_bc(args, devices, host, comm)
         helper.green_msg(f'Putative barcode table saved in {args.out_raw_bc_fn}', printit=True)
         add_summary(bc_search_qc_report(raw_bc_pass_count, args), args=args, write_mode='w')
 
@@ -138,8 +151,29 @@ def main(args, devices=None, host="native"):
         else:
             helper.green_msg(f'Whitelist saved as `{args.out_whitelist_fn}`!', printit=True)
 
+    if multi:
+        comm.barrier()                                # whitelist.csv is on disk for the other ranks
     if args.do_demultiplexing:
         logger.info("Assigning reads to whitelist.\n")
-        demul_count_tot, count_tot = read_assignment.assign_read(args=args, devices=devices, host=host)
+        if multi:
+            demul_count_tot, count_tot = _assign_sharded(args, devices, comm)
+        else:
+            demul_count_tot, count_tot = read_assignment.assign_read(args=args, devices=devices, host=host)
         add_summary(f'\nTotal reads: {count_tot}'
                     f'\nTotal reads in cells: {demul_count_tot} ({demul_count_tot / count_tot * 100:.2f}%)', args, write_mode='a')
+
+
+def _assign_sharded(args, devices, comm):
+    from . import dist
+    return dist.assign_read_sharded(comm, args.fastq_fns, args.output_fastq, args.out_raw_bc_fn, args.out_whitelist_fn,
+                                    args.max_edit_distance, args.threads, args.batch_size, restrand=args.restrand,
+                                    device=read_assignment._device_ids(devices)[0])
+
+
+def _main_worker_rank(args, devices, comm):
+    """Ranks > 0 of a multi-GPU run: their share of stages 1 and 3, in step with rank 0's collectives."""
+    if args.do_bc_search:
+        search_putative_bc(args, devices, "native", comm)
+    comm.barrier()                                    # rank 0 has written whitelist.csv (or skipped whitelisting)
+    if args.do_demultiplexing:
+        _assign_sharded(args, devices, comm)

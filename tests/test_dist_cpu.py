@@ -63,7 +63,22 @@ FILE_WORKER = textwrap.dedent("""
         return n // 2, n
     demul, total = dist.assign_read_sharded(comm, fns, os.path.join(d, "out.fastq"), "unused.csv", "unused.txt", 2, 1, 1000,
                                             count_reads=count, run_rank=run_rank)
+    # stage 1 the same way: every part starts with the header, the merged table has one
+    def run_s1(files, out):
+        n = 0
+        with open(out, "w") as o:
+            o.write("read_id,putative_bc\\n")
+            for f in files:
+                for line in open(f):
+                    if line.startswith("@"):
+                        o.write(line[1:].strip() + ",\\n"); n += 1
+        return {0: n - 1, 1: 1}
+    got = dist.putative_bc_files_sharded(comm, fns, os.path.join(d, "table.csv"), "3v3", 12, 15, 1000, 1, run_rank=run_s1)
     reads = [3, 1000, 7, 2000, 11]                 # per file (f1 and f3 are the big ones)
+    assert got == {0: sum(reads) - 2, 1: 2}, got
+    if comm.rank == 0:
+        rows = open(os.path.join(d, "table.csv")).read().split()
+        assert rows == ["read_id,putative_bc"] + ["f%%d_%%d," %% (k, i) for k in range(5) for i in range(reads[k])]
     assert total == sum(reads), total
     if comm.rank == 0:
         assert seen["files"] == ["f0.fastq", "f1.fastq", "f2.fastq"] and seen["skip"] == 0, seen

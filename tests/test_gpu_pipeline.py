@@ -79,3 +79,60 @@ def test_stage_gating_follows_the_namespace(tmp_path):
     assert not os.path.exists(args.output_fastq)
     with pytest.raises(TypeError):
         bmain.main("--expect-cells 10 reads/")
+
+
+TWO_RANK_WORKER = '''
+import json, os, sys
+sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(%r, "tests"))
+import torch.distributed as td
+from blaze_amd import dist, main as bmain
+import test_gpu_pipeline as T
+td.init_process_group("gloo", init_method="env://")
+comm = dist.TorchComm()                      # host-side sums only; the data path has no collective
+case = [c for c in T._cases() if c["name"] == sys.argv[2]][0]
+args = T._namespace(case, sys.argv[1])
+bmain.main(args, devices=[0], comm=comm)     # both ranks share the box's one GPU
+comm.barrier()
+print("rank", comm.rank, "ok")
+'''
+
+
+def _namespace(case, tmp):
+    def sub(v):
+        if isinstance(v, str):
+            return float("inf") if v == "inf" else v.replace("<TMP>", tmp)
+        if isinstance(v, list):
+            return [sub(x) for x in v]
+        return v
+    return SimpleNamespace(**{k: sub(v) for k, v in case["args"].items()})
+
+
+@pytest.mark.parametrize("name", ["3v3_expect_cells_gz", "5v2_count_threshold_plain_norestrand"])
+def test_pipeline_two_processes_shard_the_files(tmp_path, name):
+    """One process per rank (two ranks on the box's one GPU, gloo for the host-side sums): stages 1 and 3 shard the
+    FASTQ files, stage 2 is rank 0's; every file on disk equals what the REAL reference wrote in one process."""
+    import socket
+    import subprocess
+    import sys
+    case = [c for c in _cases() if c["name"] == name][0]
+    args = _materialise(case, str(tmp_path))
+    script = tmp_path / "two_rank_worker.py"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script.write_text(TWO_RANK_WORKER % (root, root))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), str(tmp_path), name], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert f"rank {rank} ok" in out
+    got = _read_outputs(args)
+    for key, expect in case["expect"].items():
+        assert got[key] == expect, f"{name}: {key} differs"
+    assert not [f for f in os.listdir(tmp_path / "out") if ".part" in f]

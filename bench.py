@@ -56,12 +56,28 @@ class Plumbing:
     def __init__(self, eng, rank, world):
         self.rank, self.world, self.kind, self.eng, self.seq = rank, world, "local", eng, 0
         self.rccl = None
+        self.hung = False
         if world > 1:
-            try:
-                self.rccl = dist.RcclComm(eng, rank, world)
-                self.kind = "rccl"
-            except Exception as e:          # noqa: BLE001  (keep the bench alive, say what happened)
-                self.kind = f"file-fallback ({type(e).__name__}: {e})"[:200]
+            # RCCL's init is collective and cannot be cancelled: run it on a daemon thread with a deadline, so that a
+            # bootstrap that never completes costs 90 s and a file-fallback line instead of the whole measurement
+            import threading
+            box = {}
+
+            def init():
+                try:
+                    box["comm"] = dist.RcclComm(eng, rank, world)
+                except Exception as e:      # noqa: BLE001  (keep the bench alive, say what happened)
+                    box["err"] = e
+            t = threading.Thread(target=init, daemon=True)
+            t.start()
+            t.join(float(os.environ.get("BLAZE_AMD_RCCL_INIT_TIMEOUT", "90")))
+            if "comm" in box:
+                self.rccl, self.kind = box["comm"], "rccl"
+            elif "err" in box:
+                self.kind = f"file-fallback ({type(box['err']).__name__}: {box['err']})"[:200]
+            else:
+                self.hung = True
+                self.kind = "file-fallback (RCCL init did not finish in time)"
 
     def gather(self, value):
         self.seq += 1
@@ -153,7 +169,16 @@ def main():
     device = local_rank % max(n_dev, 1)
     eng = Engine(device)
     info = device_info(device)
-    plumb = Plumbing(eng, rank, world)
+    # librccl prints a version banner on stdout when it initialises: keep stdout for the one JSON line
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        plumb = Plumbing(eng, rank, world)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
 
     # ---- synthetic workload, a different read shard per rank, same whitelist
     full = synth.full_whitelist_codes(400_000, seed=1)       # stand-in pool for the 6.8M 10x list
@@ -257,6 +282,8 @@ def main():
 
     if rank != 0:
         plumb.barrier()
+        if plumb.hung:
+            os._exit(0)                     # a thread is still inside RCCL's init: do not wait for it at exit
         return
 
     def roofline(kernels, ms, t, note):
@@ -323,8 +350,10 @@ def main():
         hit, *_ = eng.fetch(0)
         base["gpu_matches_oracle_on_sample"] = bool(np.array_equal(hit[:n_chk], o_hit))
         out["cpu_baseline"] = base
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     plumb.barrier()
+    if plumb.hung:
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -300,8 +300,9 @@ int launch_pair_two_kernels(bz_handle h, Slot &s) {
         s.cand_words = (int64_t)(h->pair_cap + 1) * rows;
     }
     s.cand_stride = stride;
-    const int ga = (int)((s.n + bz::kCandThreads - 1) / bz::kCandThreads);
-    hipLaunchKernelGGL(bz::k_pair_candidates, dim3(ga), dim3(bz::kCandThreads), 0, s.stream, h->d_pair_bitmap, h->d_pair_tab8,
+    const int64_t groups = (s.n + bz::kCandRowsPerBlock - 1) / bz::kCandRowsPerBlock;
+    const int ga = (int)std::min<int64_t>(groups, (int64_t)2 * h->n_cu);          // persistent: 2 workgroups of 12 waves per CU (24 of its 32 wave slots)
+    hipLaunchKernelGGL(bz::k_pair_candidates, dim3(ga), dim3(bz::kCandWThreads), 0, s.stream, h->d_pair_bitmap, h->d_pair_tab8,
                        h->d_pair_members, (int)h->n_wl, s.d_ext, s.stride, s.d_fast, s.d_counters, s.d_cand, stride, h->pair_cap,
                        s.d_cand_cnt);
     if (h->profile) HIP_TRY(hipEventRecord(s.ev[5], s.stream));

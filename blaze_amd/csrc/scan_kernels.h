@@ -637,12 +637,11 @@ constexpr int kPairTab = 65537;
 // The pair-seeded scan as two kernels (product path for max_ed == 2 while the candidate lists fit,
 // i.e. whitelists up to ~45k barcodes; above that k_pair_stream verifies straight out of the buckets):
 //
-//   k_pair_candidates : lane = row of the work list.  Needs the text's 2-bit codes only (2 VGPRs, no bit-plane
-//       masks), so 8 waves per SIMD hide the two dependent gathers per occupied bucket.  Probes the six LDS
-//       bitmaps, turns occupied buckets into barcode indices through `tab8` (entry = {count, only member or
-//       offset into members}: 96 % of the occupied buckets of a 5k list hold one barcode and need no second
-//       gather; entry = {size | offset << 8, first member}) and writes them to cand[s][slot] (s-th candidate of list slot `slot`: lanes of a wave write the
-//       same s at about the same time, so the 4-byte stores merge in L2 and k_pair_verify reads them coalesced).
+//   k_pair_candidates : one wave per (64 rows of the work list, pair).  Needs the text's 2-bit codes only (2 VGPRs,
+//       no bit-plane masks).  Probes its pair's LDS bitmap, turns occupied buckets into barcode indices through `tab8`
+//       (entry = {size | offset << 8, first member}: 96 % of the occupied buckets of a 5k list hold one barcode and
+//       need no second gather) and writes them to cand[s][slot] (s-th candidate of list slot `slot`, s handed out by a
+//       per-row LDS counter shared by the row's six waves; k_pair_verify reads the matrix coalesced).
 //   k_pair_verify<K>  : lane = row.  Two candidates per round through the packed K-error automaton; of the accepting
 //       candidates only the two smallest indices per distance class are kept (all the ordered fold can consume, see
 //       k_pair_stream) and get their exact (ed, end) in at most six rounds at the end (a true match is met through 3-6
@@ -650,128 +649,118 @@ constexpr int kPairTab = 65537;
 //       by whitelist index and the reference's order-dependent fold is replayed.  Rows with more candidates than `cap`
 //       go to redo_list (k_scan_filtered finishes them in whitelist order).
 constexpr uint32_t kCandOverflow = 0xFFFFFFFFu;
-constexpr int kCandThreads = 1024;
-constexpr int kCandPop = 8;                                       // hits decoded per lane and pair in the straight-line part
+constexpr int kCandPop = 8;                                       // bucket look-ups a lane keeps in flight per trip
 
-// lane = row.  Straight-line per pair: 27 bitmap probes -> up to kCandPop hits popped -> their bucket look-ups ISSUED;
-// the look-ups of the previous pair are CONSUMED only after that, so a wave always has one pair's gathers in flight
-// while it probes the next (the first version waited on every step of every pair: 63 us at 4.5 waves per SIMD with
-// nothing saturated).  Lanes with more than kCandPop hits in one pair (rare) finish them in a small loop.
-__global__ __launch_bounds__(kCandThreads) void k_pair_candidates(
+// Candidate generation with one WAVE per (64 rows, pair): a workgroup of 12 waves = 2 x 64 rows x 6 pairs shares
+// the six bitmaps in LDS, every wave runs ONE pair's straight-line code (wave-uniform switch), and a row's candidate
+// slots are handed out by an LDS counter (the order of a row's candidates does not matter: k_pair_verify keeps the two
+// smallest accepted indices per class).  With lane = row the kernel was one round of 4.5 waves per SIMD whose length was
+// the six pairs back to back (51 us per 293K rows; half the rows took as long); this form has six times as many waves,
+// each a sixth as long, six resident per SIMD: 43 us.  Persistent workgroups: the 48 KB of bitmaps are loaded once per
+// workgroup.
+constexpr int kCandWaves = 12;
+constexpr int kCandWThreads = kCandWaves * 64;
+constexpr int kCandRowsPerBlock = (kCandWaves / kPairCount) * 64;
+
+__global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
     const uint32_t *__restrict__ bitmap, const uint2 *__restrict__ tab8, const uint2 *__restrict__ members8, int n_wl,
     const uint8_t *__restrict__ ext, int ext_stride, const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr,
     uint32_t *__restrict__ cand, int cand_stride, int cap, uint32_t *__restrict__ cand_cnt) {
     __shared__ uint32_t bm[kPairCount * kPairBmWords];
+    __shared__ uint32_t row_cnt[kCandRowsPerBlock];
     const int n_list = *n_list_ptr;
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x * kCandThreads >= n_list) return;         // workgroup-uniform
-    {                                                             // 48 KB of bitmaps, every 16-byte load in flight at once
-        constexpr int kVec = kPairCount * kPairBmWords / 4 / kCandThreads;
-        static_assert(kVec * 4 * kCandThreads == kPairCount * kPairBmWords, "bitmap size must divide");
-        uint4 v[kVec];
-#pragma unroll
-        for (int i = 0; i < kVec; ++i) v[i] = ((const uint4 *)bitmap)[i * kCandThreads + tid];
-#pragma unroll
-        for (int i = 0; i < kVec; ++i) ((uint4 *)bm)[i * kCandThreads + tid] = v[i];
-    }
-    __syncthreads();
-    const int slot = blockIdx.x * kCandThreads + tid;
-    if ((slot & ~63) >= n_list) return;                           // whole wave idle
-    const bool active = slot < n_list;
-    const int r = list[active ? slot : n_list - 1];
-
-    uint64_t tc = 0;                                              // 2-bit codes of the text, column j at bits 2j
-    {
-        const RowBytes rb = load_row_packed(ext + (size_t)r * ext_stride);   // bytes past the text are zero: 'A' padding,
-#pragma unroll                                                               // which can only add candidates
-        for (int j = 0; j < kTextCols; ++j) tc |= (uint64_t)base_code(rb.at(j)) << (2 * j);
-    }
-    const uint32_t tlo_ = (uint32_t)tc, thi_ = (uint32_t)(tc >> 32);
-    uint32_t cnt = 0;
-    uint32_t *out = cand + slot;
-
-    // one bucket entry -> candidate slots (e.x = bucket size (saturating) | offset << 8, e.y = first member)
-    auto consume = [&](uint2 e, bool h, const uint2 *mp) {
-        const uint32_t n_mem = h ? (e.x & 0xFFu) : 0u;
-        if (n_mem) {
-            out[(size_t)min(cnt, (uint32_t)cap) * cand_stride] = e.y;          // row `cap` of the matrix is a dump row
-            ++cnt;
-            if (n_mem > 1u) {                                     // rare for small whitelists
-                if (n_mem == 0xFFu) cnt = 0x40000000u;            // saturated size: let the ordered scan do this row
-                else for (uint32_t k = 1; k < n_mem; ++k) {
-                    out[(size_t)min(cnt, (uint32_t)cap) * cand_stride] = mp[(e.x >> 8) + k].x;
-                    ++cnt;
-                }
-            }
+    if ((int)blockIdx.x * kCandRowsPerBlock >= n_list) return;    // workgroup-uniform
+    for (int i = tid; i < kPairCount * kPairBmWords / 4; i += kCandWThreads) ((uint4 *)bm)[i] = ((const uint4 *)bitmap)[i];
+    const int wave = tid >> 6, lane = tid & 63;
+    const int p_mine = wave % kPairCount, rg = wave / kPairCount; // this wave's pair and which 64 rows of the workgroup's 128
+    uint32_t *const my_cnt = &row_cnt[rg * 64 + lane];
+    for (int g = blockIdx.x; g * kCandRowsPerBlock < n_list; g += gridDim.x) {      // workgroup-uniform trip count
+        if (tid < kCandRowsPerBlock) row_cnt[tid] = 0;
+        __syncthreads();                                          // bitmaps loaded (first trip), counters cleared
+        const int slot = g * kCandRowsPerBlock + rg * 64 + lane;
+        const bool active = slot < n_list;
+        const int r = list[active ? slot : n_list - 1];
+        uint64_t tc = 0;                                          // 2-bit codes of the text, column j at bits 2j
+        {
+            const RowBytes rb = load_row_packed(ext + (size_t)r * ext_stride);   // bytes past the text are zero: 'A' padding,
+#pragma unroll                                                                   // which can only add candidates
+            for (int j = 0; j < kTextCols; ++j) tc |= (uint64_t)base_code(rb.at(j)) << (2 * j);
         }
-    };
-    uint2 e_prev[kCandPop];
-    bool h_prev[kCandPop];
-#pragma unroll
-    for (int q = 0; q < kCandPop; ++q) { e_prev[q] = make_uint2(0u, 0u); h_prev[q] = false; }
-    const uint2 *mp_prev = members8;
+        const uint32_t tlo = (uint32_t)tc, thi = (uint32_t)(tc >> 32);
+        uint32_t *out = cand + slot;
 
-    auto do_pair = [&](auto pa_c, auto pb_c, auto p_c) {
-        constexpr int a = decltype(pa_c)::value, b = decltype(pb_c)::value, p = decltype(p_c)::value;
-        uint32_t mlo = 0, mhi = 0;                                // bit (5 xi + di) <=> windows (ja, jb) name an occupied bucket
-        const uint32_t tlo = in_vgpr(tlo_), thi = in_vgpr(thi_);  // opaque: no cross-pair hoisting of window codes
-#pragma unroll
-        for (int xi = 0; xi < 9; ++xi) {
-#pragma unroll
-            for (int di = 0; di < 5; ++di) {
-                const int ja = 4 * a - 2 + xi, jb = ja + 4 * (b - a) + di - 2;
-                const bool ok = pair_probe_ok(a, b, xi, di);
-                if (ok) {
-                    const uint32_t ca = 2 * ja + 8 <= 32 ? (tlo >> (2 * ja)) : 2 * ja >= 32 ? (thi >> ((2 * ja) & 31)) : __builtin_amdgcn_alignbit(thi, tlo, (2 * ja) & 31);
-                    const uint32_t cb = 2 * jb + 8 <= 32 ? (tlo >> (2 * jb)) : 2 * jb >= 32 ? (thi >> ((2 * jb) & 31)) : __builtin_amdgcn_alignbit(thi, tlo, (2 * jb) & 31);
-                    const uint32_t key = ((ca & 0xFFu) << 8) | (cb & 0xFFu);
-                    const uint32_t w = bm[p * kPairBmWords + (key >> 5)];
-                    const uint32_t bit = (w >> (key & 31u)) & 1u;
-                    const int pos = 5 * xi + di;
-                    if (pos < 32) mlo |= bit << (pos & 31); else mhi |= bit << ((pos - 32) & 31);
-                }
+        // one bucket entry -> candidate slots (e.x = bucket size (saturating) | offset << 8, e.y = first member)
+        auto consume = [&](uint2 e, bool h, const uint2 *mp) {
+            const uint32_t n_mem = h ? (e.x & 0xFFu) : 0u;
+            if (n_mem) {
+                if (n_mem == 0xFFu) { atomicAdd(my_cnt, 0x40000000u); return; }   // saturated size: let the ordered scan do this row
+                const uint32_t base = atomicAdd(my_cnt, n_mem);
+                out[(size_t)min(base, (uint32_t)cap) * cand_stride] = e.y;       // row `cap` of the matrix is a dump row
+                for (uint32_t k = 1; k < n_mem; ++k)                             // rare for small whitelists
+                    out[(size_t)min(base + k, (uint32_t)cap) * cand_stride] = mp[(e.x >> 8) + k].x;
             }
-        }
-        if (!active) { mlo = 0; mhi = 0; }
-        const uint2 *tp = tab8 + (size_t)p * 65536;
-        const uint2 *mp = members8 + (size_t)p * n_wl;
-        const uint64_t tcc = ((uint64_t)thi << 32) | tlo;
-        auto pop = [&](bool &h) -> uint32_t {                     // next hit of this lane -> its 16-bit key
-            const bool lo = mlo != 0;
-            const uint32_t w = lo ? mlo : mhi;
-            h = w != 0;
-            const int pos = (int)__builtin_ctz(w | 0x80000000u) + (lo ? 0 : 32);
-            const uint32_t w2 = w & (w - 1u);
-            mlo = lo ? w2 : mlo;
-            mhi = lo ? mhi : w2;
-            const int xi = (pos * 13) >> 6, di = pos - 5 * xi;    // pos / 5, pos % 5 for pos < 64
-            const int ja = 4 * a - 2 + xi, jb = ja + 4 * (b - a) + di - 2;
-            return (((uint32_t)(tcc >> ((2 * ja) & 63)) & 0xFFu) << 8) | ((uint32_t)(tcc >> ((2 * jb) & 63)) & 0xFFu);
         };
-        uint2 e[kCandPop];
-        bool h[kCandPop];
+        auto do_pair = [&](auto pa_c, auto pb_c, auto p_c) {
+            constexpr int a = decltype(pa_c)::value, b = decltype(pb_c)::value, p = decltype(p_c)::value;
+            uint32_t mlo = 0, mhi = 0;                            // bit (5 xi + di) <=> windows (ja, jb) name an occupied bucket
 #pragma unroll
-        for (int q = 0; q < kCandPop; ++q) {                      // issue this pair's look-ups ...
-            const uint32_t key = pop(h[q]);
-            e[q] = tp[h[q] ? key : 0u];
-        }
+            for (int xi = 0; xi < 9; ++xi) {
 #pragma unroll
-        for (int q = 0; q < kCandPop; ++q) consume(e_prev[q], h_prev[q], mp_prev);   // ... then retire the previous pair's
-        while (__builtin_amdgcn_ballot_w64((mlo | mhi) != 0) != 0) {                 // rare: more than kCandPop hits in one pair
-            bool hh;
-            const uint32_t key = pop(hh);
-            consume(tp[hh ? key : 0u], hh, mp);
-        }
+                for (int di = 0; di < 5; ++di) {
+                    const int ja = 4 * a - 2 + xi, jb = ja + 4 * (b - a) + di - 2;
+                    if (pair_probe_ok(a, b, xi, di)) {
+                        const uint32_t ca = 2 * ja + 8 <= 32 ? (tlo >> (2 * ja)) : 2 * ja >= 32 ? (thi >> ((2 * ja) & 31)) : __builtin_amdgcn_alignbit(thi, tlo, (2 * ja) & 31);
+                        const uint32_t cb = 2 * jb + 8 <= 32 ? (tlo >> (2 * jb)) : 2 * jb >= 32 ? (thi >> ((2 * jb) & 31)) : __builtin_amdgcn_alignbit(thi, tlo, (2 * jb) & 31);
+                        const uint32_t key = ((ca & 0xFFu) << 8) | (cb & 0xFFu);
+                        const uint32_t w = bm[p * kPairBmWords + (key >> 5)];
+                        const uint32_t bit = (w >> (key & 31u)) & 1u;
+                        const int pos = 5 * xi + di;
+                        if (pos < 32) mlo |= bit << (pos & 31); else mhi |= bit << ((pos - 32) & 31);
+                    }
+                }
+            }
+            if (!active) { mlo = 0; mhi = 0; }
+            const uint2 *tp = tab8 + (size_t)p * 65536;
+            const uint2 *mp = members8 + (size_t)p * n_wl;
+            auto pop = [&](bool &h) -> uint32_t {                 // next hit of this lane -> its 16-bit key
+                const bool lo = mlo != 0;
+                const uint32_t w = lo ? mlo : mhi;
+                h = w != 0;
+                const int pos = (int)__builtin_ctz(w | 0x80000000u) + (lo ? 0 : 32);
+                const uint32_t w2 = w & (w - 1u);
+                mlo = lo ? w2 : mlo;
+                mhi = lo ? mhi : w2;
+                const int xi = (pos * 13) >> 6, di = pos - 5 * xi;    // pos / 5, pos % 5 for pos < 64
+                const int ja = 4 * a - 2 + xi, jb = ja + 4 * (b - a) + di - 2;
+                return (((uint32_t)(tc >> ((2 * ja) & 63)) & 0xFFu) << 8) | ((uint32_t)(tc >> ((2 * jb) & 63)) & 0xFFu);
+            };
+            while (__builtin_amdgcn_ballot_w64((mlo | mhi) != 0) != 0) {             // usually one trip: <= kCandPop hits per lane
+                uint2 e[kCandPop];
+                bool h[kCandPop];
 #pragma unroll
-        for (int q = 0; q < kCandPop; ++q) { e_prev[q] = e[q]; h_prev[q] = h[q]; }
-        mp_prev = mp;
-    };
+                for (int q = 0; q < kCandPop; ++q) {              // all look-ups of the trip in flight together
+                    const uint32_t key = pop(h[q]);
+                    e[q] = tp[h[q] ? key : 0u];
+                }
+#pragma unroll
+                for (int q = 0; q < kCandPop; ++q) consume(e[q], h[q], mp);
+            }
+        };
 #define BZ_PAIR(A, B, P) do_pair(std::integral_constant<int, A>{}, std::integral_constant<int, B>{}, std::integral_constant<int, P>{})
-    BZ_PAIR(0, 1, 0); BZ_PAIR(0, 2, 1); BZ_PAIR(0, 3, 2); BZ_PAIR(1, 2, 3); BZ_PAIR(1, 3, 4); BZ_PAIR(2, 3, 5);
+        switch (p_mine) {                                         // wave-uniform
+            case 0: BZ_PAIR(0, 1, 0); break;
+            case 1: BZ_PAIR(0, 2, 1); break;
+            case 2: BZ_PAIR(0, 3, 2); break;
+            case 3: BZ_PAIR(1, 2, 3); break;
+            case 4: BZ_PAIR(1, 3, 4); break;
+            default: BZ_PAIR(2, 3, 5); break;
+        }
 #undef BZ_PAIR
-#pragma unroll
-    for (int q = 0; q < kCandPop; ++q) consume(e_prev[q], h_prev[q], mp_prev);
-    if (active) cand_cnt[slot] = cnt > (uint32_t)cap ? kCandOverflow : cnt;
+        __syncthreads();                                          // the six waves of a row group are done with its counters
+        if (p_mine == 0 && active) { const uint32_t c = *my_cnt; cand_cnt[slot] = c > (uint32_t)cap ? kCandOverflow : c; }
+        __syncthreads();                                          // ... read before the next trip clears them
+    }
 }
 
 template <int K>

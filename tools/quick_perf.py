@@ -32,7 +32,7 @@ for shortcut, mode in ((1, 0), (0, 0), (1, 3), (0, 3)):
         t0 = time.time(); eng.run(0, 2); eng.sync(0); wall = time.time() - t0
         t = eng.timing(0)
         pairs = t["rows_bitparallel"] * n_wl
-        print(f"mode={mode} shortcut={shortcut} wall {wall*1e3:.2f} ms total {t['total_ms']:.2f} classify {t['classify_ms']:.3f} scan {t['scan_ms']:.2f} "
+        print(f"mode={mode} shortcut={shortcut} wall {wall*1e3:.2f} ms total {t['total_ms']:.2f} classify {t['classify_ms']:.3f} scan {t['scan_ms']:.3f} (cand {t['candidates_ms']:.4f} verify {t['verify_ms']:.4f}) "
               f"gen {t['generic_ms']:.3f} hist {t['hist_ms']:.3f} scored {t['rows_bitparallel']} redo {t['rows_redo']} "
               f"-> {n_rows/ (t['total_ms']*1e-3)/1e6:.2f} M reads/s, {pairs/(t['scan_ms']*1e-3)/1e9:.1f} G pairs/s, "
               f"{pairs*340/(t['scan_ms']*1e-3)/1e12:.2f} T alg-ops/s")

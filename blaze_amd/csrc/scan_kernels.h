@@ -661,6 +661,7 @@ constexpr int kCandPop = 8;                                       // bucket look
 constexpr int kCandWaves = 12;
 constexpr int kCandWThreads = kCandWaves * 64;
 constexpr int kCandRowsPerBlock = (kCandWaves / kPairCount) * 64;
+constexpr int kCandSeen = 16;                                     // memo entries per row (power of two)
 
 __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
     const uint32_t *__restrict__ bitmap, const uint2 *__restrict__ tab8, const uint2 *__restrict__ members8, int n_wl,
@@ -668,6 +669,7 @@ __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
     uint32_t *__restrict__ cand, int cand_stride, int cap, uint32_t *__restrict__ cand_cnt) {
     __shared__ uint32_t bm[kPairCount * kPairBmWords];
     __shared__ uint32_t row_cnt[kCandRowsPerBlock];
+    __shared__ uint32_t seen[kCandSeen][kCandRowsPerBlock];       // per row: the last index listed per hash class (bank = row)
     const int n_list = *n_list_ptr;
     const int tid = threadIdx.x;
     if ((int)blockIdx.x * kCandRowsPerBlock >= n_list) return;    // workgroup-uniform
@@ -677,6 +679,7 @@ __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
     uint32_t *const my_cnt = &row_cnt[rg * 64 + lane];
     for (int g = blockIdx.x; g * kCandRowsPerBlock < n_list; g += gridDim.x) {      // workgroup-uniform trip count
         if (tid < kCandRowsPerBlock) row_cnt[tid] = 0;
+        for (int i = tid; i < kCandSeen * kCandRowsPerBlock; i += kCandWThreads) (&seen[0][0])[i] = 0xFFFFFFFFu;
         __syncthreads();                                          // bitmaps loaded (first trip), counters cleared
         const int slot = g * kCandRowsPerBlock + rg * 64 + lane;
         const bool active = slot < n_list;
@@ -691,14 +694,23 @@ __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
         uint32_t *out = cand + slot;
 
         // one bucket entry -> candidate slots (e.x = bucket size (saturating) | offset << 8, e.y = first member)
+        // A true barcode is met through 3-6 of the pairs, i.e. by several of this row's waves: `seen` is a direct-mapped
+        // memo of the indices already listed for the row (exact compare, so it can only drop real repeats; a repeat that
+        // slips through -- two waves listing the same index at the same moment, or an evicted entry -- is harmless:
+        // k_pair_verify ignores an index it already keeps).  ~14 -> ~10 candidates per row of a 5k-cell list.
+        auto emit = [&](uint32_t idx) {
+            uint32_t *const sp = &seen[idx & (kCandSeen - 1)][rg * 64 + lane];
+            if (*sp == idx) return;
+            *sp = idx;
+            const uint32_t base = atomicAdd(my_cnt, 1u);
+            out[(size_t)min(base, (uint32_t)cap) * cand_stride] = idx;          // row `cap` of the matrix is a dump row
+        };
         auto consume = [&](uint2 e, bool h, const uint2 *mp) {
             const uint32_t n_mem = h ? (e.x & 0xFFu) : 0u;
             if (n_mem) {
                 if (n_mem == 0xFFu) { atomicAdd(my_cnt, 0x40000000u); return; }   // saturated size: let the ordered scan do this row
-                const uint32_t base = atomicAdd(my_cnt, n_mem);
-                out[(size_t)min(base, (uint32_t)cap) * cand_stride] = e.y;       // row `cap` of the matrix is a dump row
-                for (uint32_t k = 1; k < n_mem; ++k)                             // rare for small whitelists
-                    out[(size_t)min(base + k, (uint32_t)cap) * cand_stride] = mp[(e.x >> 8) + k].x;
+                emit(e.y);
+                for (uint32_t k = 1; k < n_mem; ++k) emit(mp[(e.x >> 8) + k].x);  // rare for small whitelists
             }
         };
         auto do_pair = [&](auto pa_c, auto pb_c, auto p_c) {

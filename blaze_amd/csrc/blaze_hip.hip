@@ -86,6 +86,7 @@ struct Slot {
     // device
     uint8_t *d_ext = nullptr, *d_len = nullptr, *d_off = nullptr, *d_bcl = nullptr, *d_flags = nullptr;
     int32_t *d_hit = nullptr, *d_fast = nullptr, *d_gen = nullptr, *d_redo = nullptr, *d_counters = nullptr;
+    void *d_fast_tc = nullptr;             // uint2 per fast_list slot: the text's 2-bit codes + length (k_classify_packed -> pair kernels)
     int8_t *d_ed = nullptr, *d_end = nullptr;
     uint32_t *d_cand = nullptr, *d_cand_cnt = nullptr;   // candidate lists of the pair-seeded scan: cand[s][slot], cap x cand_stride
     int64_t cand_words = 0;
@@ -178,12 +179,12 @@ void free_whitelist(bz_handle h) {
 
 void free_slot(Slot &s) {
     hipFree(s.d_ext); hipFree(s.d_len); hipFree(s.d_off); hipFree(s.d_bcl); hipFree(s.d_flags);
-    hipFree(s.d_hit); hipFree(s.d_fast); hipFree(s.d_gen); hipFree(s.d_redo); hipFree(s.d_ed); hipFree(s.d_end);
+    hipFree(s.d_hit); hipFree(s.d_fast); hipFree(s.d_gen); hipFree(s.d_redo); hipFree(s.d_fast_tc); hipFree(s.d_ed); hipFree(s.d_end);
     hipHostFree(s.h_in); hipHostFree(s.h_out);
     hipFree(s.d_cand); hipFree(s.d_cand_cnt);
     s.d_cand = s.d_cand_cnt = nullptr; s.cand_words = 0; s.cand_stride = 0;
     s.d_ext = s.d_len = s.d_off = s.d_bcl = s.d_flags = nullptr;
-    s.d_hit = s.d_fast = s.d_gen = s.d_redo = nullptr;
+    s.d_hit = s.d_fast = s.d_gen = s.d_redo = nullptr; s.d_fast_tc = nullptr;
     s.d_ed = s.d_end = nullptr;
     s.h_in = s.h_out = nullptr;
     s.cap = 0; s.cap_stride = 0;
@@ -244,6 +245,7 @@ int ensure_slot(Slot &s, int64_t n, int stride) {
     HIP_TRY(hipMalloc(&s.d_flags, cap)); HIP_TRY(hipMalloc(&s.d_ed, cap)); HIP_TRY(hipMalloc(&s.d_end, cap));
     HIP_TRY(hipMalloc(&s.d_hit, cap * 4)); HIP_TRY(hipMalloc(&s.d_fast, cap * 4)); HIP_TRY(hipMalloc(&s.d_gen, cap * 4));
     HIP_TRY(hipMalloc(&s.d_redo, cap * 4));
+    HIP_TRY(hipMalloc(&s.d_fast_tc, cap * 8));
     HIP_TRY(hipHostMalloc(&s.h_in, (size_t)cap * (cs + 3), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(&s.h_out, (size_t)cap * 7, hipHostMallocDefault));
     s.cap = cap; s.cap_stride = cs;
@@ -303,13 +305,13 @@ int launch_pair_two_kernels(bz_handle h, Slot &s) {
     const int64_t groups = (s.n + bz::kCandRowsPerBlock - 1) / bz::kCandRowsPerBlock;
     const int ga = (int)std::min<int64_t>(groups, (int64_t)2 * h->n_cu);          // persistent: 2 workgroups of 12 waves per CU (24 of its 32 wave slots)
     hipLaunchKernelGGL(bz::k_pair_candidates, dim3(ga), dim3(bz::kCandWThreads), 0, s.stream, h->d_pair_bitmap, h->d_pair_tab8,
-                       h->d_pair_members, (int)h->n_wl, s.d_ext, s.stride, s.d_fast, s.d_counters, s.d_cand, stride, h->pair_cap,
+                       h->d_pair_members, (int)h->n_wl, (const uint2 *)s.d_fast_tc, s.d_counters, s.d_cand, stride, h->pair_cap,
                        s.d_cand_cnt);
     if (h->profile) HIP_TRY(hipEventRecord(s.ev[5], s.stream));
     const int block = 256;
     const int grid = (int)((s.n + block - 1) / block);
     hipLaunchKernelGGL(bz::k_pair_verify<2>, dim3(grid), dim3(block), 0, s.stream, s.d_cand, stride, s.d_cand_cnt, h->d_planes32,
-                       s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_redo, s.d_counters + 2, s.d_hit, s.d_ed,
+                       (const uint2 *)s.d_fast_tc, s.d_fast, s.d_counters, h->tie_rule, s.d_redo, s.d_counters + 2, s.d_hit, s.d_ed,
                        s.d_end, s.d_flags);
     if (h->profile) { HIP_TRY(hipEventRecord(s.ev[6], s.stream)); s.timed_pair = true; }
     hipLaunchKernelGGL(bz::k_scan_filtered<2>, dim3(grid), dim3(block), 0, s.stream, (const uint4 *)h->d_grams, h->d_planes32, h->n_blk,
@@ -658,7 +660,7 @@ int bz_assign_run(bz_handle h, int slot, int max_ed) {
         if ((s.stride & 15) == 0 && s.stride >= 32)
             hipLaunchKernelGGL(bz::k_classify_packed, cgrid, dim3(bz::kClassifyThreads), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
                                s.d_bcl, n, h->wl_regular, h->d_sorted_pairs, (int)h->n_wl, h->d_bucket, h->bucket_bits, h->shortcut,
-                               h->force_generic, max_ed, s.d_fast, s.d_gen, s.d_counters, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+                               h->force_generic, max_ed, s.d_fast, (uint2 *)s.d_fast_tc, s.d_gen, s.d_counters, s.d_hit, s.d_ed, s.d_end, s.d_flags);
         else
             hipLaunchKernelGGL(bz::k_classify, dim3((n + bz::kClassifyThreads * bz::kClassifyRows - 1) / (bz::kClassifyThreads * bz::kClassifyRows)), dim3(bz::kClassifyThreads), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
                            s.d_bcl, n, h->wl_regular, h->d_sorted_codes, h->d_sorted_idx, (int)h->n_wl, h->d_bucket, h->bucket_bits, h->shortcut,

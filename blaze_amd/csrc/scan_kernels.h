@@ -665,7 +665,7 @@ constexpr int kCandSeen = 16;                                     // memo entrie
 
 __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
     const uint32_t *__restrict__ bitmap, const uint2 *__restrict__ tab8, const uint2 *__restrict__ members8, int n_wl,
-    const uint8_t *__restrict__ ext, int ext_stride, const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr,
+    const uint2 *__restrict__ list_tc, const int32_t *__restrict__ n_list_ptr,
     uint32_t *__restrict__ cand, int cand_stride, int cap, uint32_t *__restrict__ cand_cnt) {
     __shared__ uint32_t bm[kPairCount * kPairBmWords];
     __shared__ uint32_t row_cnt[kCandRowsPerBlock];
@@ -677,20 +677,18 @@ __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
     const int wave = tid >> 6, lane = tid & 63;
     const int p_mine = wave % kPairCount, rg = wave / kPairCount; // this wave's pair and which 64 rows of the workgroup's 128
     uint32_t *const my_cnt = &row_cnt[rg * 64 + lane];
+    // the text's codes come from k_classify_packed (list_tc[slot], one coalesced 8-byte load instead of list -> row);
+    // the next trip's are requested a trip ahead
+    uint2 t_next = list_tc[min((int)blockIdx.x * kCandRowsPerBlock + rg * 64 + lane, n_list - 1)];
     for (int g = blockIdx.x; g * kCandRowsPerBlock < n_list; g += gridDim.x) {      // workgroup-uniform trip count
         if (tid < kCandRowsPerBlock) row_cnt[tid] = 0;
         for (int i = tid; i < kCandSeen * kCandRowsPerBlock; i += kCandWThreads) (&seen[0][0])[i] = 0xFFFFFFFFu;
         __syncthreads();                                          // bitmaps loaded (first trip), counters cleared
         const int slot = g * kCandRowsPerBlock + rg * 64 + lane;
         const bool active = slot < n_list;
-        const int r = list[active ? slot : n_list - 1];
-        uint64_t tc = 0;                                          // 2-bit codes of the text, column j at bits 2j
-        {
-            const RowBytes rb = load_row_packed(ext + (size_t)r * ext_stride);   // bytes past the text are zero: 'A' padding,
-#pragma unroll                                                                   // which can only add candidates
-            for (int j = 0; j < kTextCols; ++j) tc |= (uint64_t)base_code(rb.at(j)) << (2 * j);
-        }
-        const uint32_t tlo = (uint32_t)tc, thi = (uint32_t)(tc >> 32);
+        const uint32_t tlo = t_next.x, thi = t_next.y & 0xFFu;    // 2-bit codes of the text, column j at bits 2j; 'A' padding past
+        const uint64_t tc = (uint64_t)tlo | ((uint64_t)thi << 32);   // its end, which can only add candidates
+        t_next = list_tc[min(slot + (int)gridDim.x * kCandRowsPerBlock, n_list - 1)];
         uint32_t *out = cand + slot;
 
         // one bucket entry -> candidate slots (e.x = bucket size (saturating) | offset << 8, e.y = first member)
@@ -778,32 +776,60 @@ __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
 template <int K>
 __global__ __launch_bounds__(256) void k_pair_verify(
     const uint32_t *__restrict__ cand, int cand_stride, const uint32_t *__restrict__ cand_cnt,
-    const uint32_t *__restrict__ planes32,
-    const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
+    const uint32_t *__restrict__ planes32, const uint2 *__restrict__ list_tc,
     const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int tie,
     int32_t *__restrict__ redo_list, int32_t *__restrict__ n_redo,
     int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
     __shared__ uint32_t events[6][256];
+    __shared__ uint32_t s_cnt[256], s_bin[64];
+    __shared__ uint16_t s_perm[256];
     const int n_list = *n_list_ptr;
     const int tid = threadIdx.x;
-    const int slot = blockIdx.x * blockDim.x + tid;
-    if ((slot & ~63) >= n_list) return;                           // whole wave idle (wave-uniform)
+    if ((int)(blockIdx.x * blockDim.x) >= n_list) return;         // workgroup-uniform
+    // A wave runs as many rounds as its fullest lane: the workgroup's 256 slots are dealt to the lanes in order of
+    // their round counts (counting sort in LDS), so each wave holds one quartile; the quartile -> wave map rotates with
+    // the workgroup so that no SIMD collects the long waves.
+    int slot;
+    uint32_t cnt_raw;
+    {
+        const int s0 = blockIdx.x * blockDim.x + tid;
+        const uint32_t c = s0 < n_list ? cand_cnt[s0] : 0u;
+        s_cnt[tid] = c;
+        if (tid < 64) s_bin[tid] = 0;
+        __syncthreads();
+        const uint32_t rounds = c == kCandOverflow ? 0u : min((c + 1u) >> 1, 63u);
+        const uint32_t pos = atomicAdd(&s_bin[rounds], 1u);
+        __syncthreads();
+        if (tid < 64) {                                           // exclusive prefix over the 64 bins (one wave)
+            const uint32_t v = s_bin[tid];
+            uint32_t x = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (tid >= d) x += y; }
+            s_bin[tid] = x - v;
+        }
+        __syncthreads();
+        s_perm[s_bin[rounds] + pos] = (uint16_t)tid;
+        __syncthreads();
+        const int mine = s_perm[(((tid >> 6) + blockIdx.x) & 3) * 64 + (tid & 63)];
+        slot = blockIdx.x * blockDim.x + mine;
+        cnt_raw = s_cnt[mine];
+    }
     const bool active = slot < n_list;
-    const int r = list[active ? slot : n_list - 1];
-    const int len = ext_len[r];
-    const uint32_t cnt_raw = active ? cand_cnt[slot] : 0u;
+    const int r = list[active ? slot : n_list - 1];              // only the result stores need it
+    const uint2 t = list_tc[active ? slot : n_list - 1];         // the text's codes + length, from k_classify_packed
+    const int len = (int)((t.y >> 8) & 0xFFu);
     bool overflow = cnt_raw == kCandOverflow;
     const uint32_t cnt = overflow ? 0u : cnt_raw;
 
     uint32_t XH[kTextCols], XL[kTextCols];
     {
-        const RowBytes rb = load_row_packed(ext + (size_t)r * ext_stride);
+        const uint32_t nlo = ~t.x, nhi = ~t.y;                    // a sign-extended 1-bit field of the inverted codes = the mask
 #pragma unroll
         for (int j = 0; j < kTextCols; ++j) {
-            const uint32_t c = (j < len) ? rb.at(j) : (uint32_t)'A';
-            const uint32_t code = base_code(c);
-            XH[j] = (code & 2u) ? 0u : 0xFFFFFFFFu;
-            XL[j] = (code & 1u) ? 0u : 0xFFFFFFFFu;
+            const uint32_t w = j < 16 ? nlo : nhi;
+            const int b = 2 * (j & 15);
+            XH[j] = (uint32_t)__builtin_amdgcn_sbfe((int)w, b + 1, 1);
+            XL[j] = (uint32_t)__builtin_amdgcn_sbfe((int)w, b, 1);
         }
     }
     const uint32_t one = in_vgpr(kOne2);
@@ -1312,7 +1338,7 @@ __global__ __launch_bounds__(kClassifyThreads) void k_classify_packed(
     const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
     const uint8_t *__restrict__ bc_off, const uint8_t *__restrict__ bc_len, int n, int wl_regular,
     const uint2 *__restrict__ sorted_pairs, int n_wl, const int32_t *__restrict__ bucket_start, int bucket_bits,
-    int shortcut, int force_generic, int max_ed, int32_t *__restrict__ fast_list,
+    int shortcut, int force_generic, int max_ed, int32_t *__restrict__ fast_list, uint2 *__restrict__ fast_tc,
     int32_t *__restrict__ gen_list, int32_t *__restrict__ counters, int32_t *__restrict__ hit_out,
     int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
     __shared__ int s_cnt[2][kClassifyRows][kClassifyWaves];   // [list][k][wave] -> exclusive offsets
@@ -1334,20 +1360,24 @@ __global__ __launch_bounds__(kClassifyThreads) void k_classify_packed(
     const bool search = wl_regular && shortcut;               // wave-uniform
     bool regular[kClassifyRows];
     uint32_t code[kClassifyRows];
+    uint2 tc[kClassifyRows];                                  // the text's 2-bit codes, column j at bits 2j ('A' past its end), len in y's bits 8..15
     int lo[kClassifyRows], hi[kClassifyRows];
 #pragma unroll
     for (int k = 0; k < kClassifyRows; ++k) {
         if (!in[k]) bl[k] = 0;
         bool ok = wl_regular && !force_generic && bl[k] == kBcLen && len[k] >= kBcLen && len[k] <= kTextCols && max_ed <= kMaxK;
-        uint32_t c16 = 0;
+        uint32_t c16 = 0, tlo = 0, thi = 0;
 #pragma unroll
         for (int j = 0; j < kTextCols; ++j) {
             const uint32_t c = rb[k].at(j);
             ok = ok && (j >= len[k] || is_acgt(c));
             const int i = j - off[k];
             if (i >= 0 && i < kBcLen && j < len[k]) c16 |= base_code(c) << (2 * i);
+            if (j < 16) tlo |= base_code(c) << (2 * j);
+            else if (j < len[k]) thi |= base_code(c) << (2 * (j - 16));
         }
         regular[k] = ok; code[k] = c16;
+        tc[k] = make_uint2(tlo, thi | ((uint32_t)len[k] << 8));
         lo[k] = 0; hi[k] = 0;
     }
     uint2 pr[kClassifyRows];
@@ -1403,7 +1433,7 @@ __global__ __launch_bounds__(kClassifyThreads) void k_classify_packed(
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kClassifyRows; ++k) {
-        if (route[k] == 1) fast_list[s_base[0] + s_cnt[0][k][wave] + pos[k]] = r[k];
+        if (route[k] == 1) { const int at = s_base[0] + s_cnt[0][k][wave] + pos[k]; fast_list[at] = r[k]; fast_tc[at] = tc[k]; }
         else if (route[k] == 2) gen_list[s_base[1] + s_cnt[1][k][wave] + pos[k]] = r[k];
     }
 }

@@ -88,7 +88,7 @@ struct Slot {
     int32_t *d_hit = nullptr, *d_fast = nullptr, *d_gen = nullptr, *d_redo = nullptr, *d_counters = nullptr;
     void *d_fast_tc = nullptr;             // uint2 per fast_list slot: the text's 2-bit codes + length (k_classify_packed -> pair kernels)
     int8_t *d_ed = nullptr, *d_end = nullptr;
-    uint32_t *d_cand = nullptr, *d_cand_cnt = nullptr;   // candidate lists of the pair-seeded scan: cand[s][slot], cap x cand_stride
+    uint32_t *d_cand = nullptr, *d_cand_cnt = nullptr;   // candidate lists of the pair-seeded scan: cand[slot / 64][s][slot % 64], tiles of (cap + 1) x 64
     int64_t cand_words = 0;
     int cand_stride = 0;
     // pinned host staging
@@ -305,12 +305,12 @@ int launch_pair_two_kernels(bz_handle h, Slot &s) {
     const int64_t groups = (s.n + bz::kCandRowsPerBlock - 1) / bz::kCandRowsPerBlock;
     const int ga = (int)std::min<int64_t>(groups, (int64_t)2 * h->n_cu);          // persistent: 2 workgroups of 12 waves per CU (24 of its 32 wave slots)
     hipLaunchKernelGGL(bz::k_pair_candidates, dim3(ga), dim3(bz::kCandWThreads), 0, s.stream, h->d_pair_bitmap, h->d_pair_tab8,
-                       h->d_pair_members, (int)h->n_wl, (const uint2 *)s.d_fast_tc, s.d_counters, s.d_cand, stride, h->pair_cap,
+                       h->d_pair_members, (int)h->n_wl, (const uint2 *)s.d_fast_tc, s.d_counters, s.d_cand, h->pair_cap,
                        s.d_cand_cnt);
     if (h->profile) HIP_TRY(hipEventRecord(s.ev[5], s.stream));
     const int block = 256;
     const int grid = (int)((s.n + block - 1) / block);
-    hipLaunchKernelGGL(bz::k_pair_verify<2>, dim3(grid), dim3(block), 0, s.stream, s.d_cand, stride, s.d_cand_cnt, h->d_planes32,
+    hipLaunchKernelGGL(bz::k_pair_verify<2>, dim3(grid), dim3(block), 0, s.stream, s.d_cand, h->pair_cap, s.d_cand_cnt, h->d_planes32,
                        (const uint2 *)s.d_fast_tc, s.d_fast, s.d_counters, h->tie_rule, s.d_redo, s.d_counters + 2, s.d_hit, s.d_ed,
                        s.d_end, s.d_flags);
     if (h->profile) { HIP_TRY(hipEventRecord(s.ev[6], s.stream)); s.timed_pair = true; }

@@ -640,7 +640,7 @@ constexpr int kPairTab = 65537;
 //   k_pair_candidates : one wave per (64 rows of the work list, pair).  Needs the text's 2-bit codes only (2 VGPRs,
 //       no bit-plane masks).  Probes its pair's LDS bitmap, turns occupied buckets into barcode indices through `tab8`
 //       (entry = {size | offset << 8, first member}: 96 % of the occupied buckets of a 5k list hold one barcode and
-//       need no second gather) and writes them to cand[s][slot] (s-th candidate of list slot `slot`, s handed out by a
+//       need no second gather) and writes them to cand[slot / 64][s][slot % 64] (s-th candidate of list slot `slot`; tiles of 64 slots x (cap + 1) rows, s handed out by a
 //       per-row LDS counter shared by the row's six waves; k_pair_verify reads the matrix coalesced).
 //   k_pair_verify<K>  : lane = row.  Two candidates per round through the packed K-error automaton; of the accepting
 //       candidates only the two smallest indices per distance class are kept (all the ordered fold can consume, see
@@ -666,7 +666,7 @@ constexpr int kCandSeen = 16;                                     // memo entrie
 __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
     const uint32_t *__restrict__ bitmap, const uint2 *__restrict__ tab8, const uint2 *__restrict__ members8, int n_wl,
     const uint2 *__restrict__ list_tc, const int32_t *__restrict__ n_list_ptr,
-    uint32_t *__restrict__ cand, int cand_stride, int cap, uint32_t *__restrict__ cand_cnt) {
+    uint32_t *__restrict__ cand, int cap, uint32_t *__restrict__ cand_cnt) {
     __shared__ uint32_t bm[kPairCount * kPairBmWords];
     __shared__ uint32_t row_cnt[kCandRowsPerBlock];
     __shared__ uint32_t seen[kCandSeen][kCandRowsPerBlock];       // per row: the last index listed per hash class (bank = row)
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
         const uint32_t tlo = t_next.x, thi = t_next.y & 0xFFu;    // 2-bit codes of the text, column j at bits 2j; 'A' padding past
         const uint64_t tc = (uint64_t)tlo | ((uint64_t)thi << 32);   // its end, which can only add candidates
         t_next = list_tc[min(slot + (int)gridDim.x * kCandRowsPerBlock, n_list - 1)];
-        uint32_t *out = cand + slot;
+        uint32_t *out = cand + (size_t)(slot >> 6) * ((size_t)(cap + 1) * 64) + (slot & 63);   // the slot's column of its 64-slot tile
 
         // one bucket entry -> candidate slots (e.x = bucket size (saturating) | offset << 8, e.y = first member)
         // A true barcode is met through 3-6 of the pairs, i.e. by several of this row's waves: `seen` is a direct-mapped
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
             if (*sp == idx) return;
             *sp = idx;
             const uint32_t base = atomicAdd(my_cnt, 1u);
-            out[(size_t)min(base, (uint32_t)cap) * cand_stride] = idx;          // row `cap` of the matrix is a dump row
+            out[min(base, (uint32_t)cap) << 6] = idx;                           // row `cap` of the tile is a dump row
         };
         auto consume = [&](uint2 e, bool h, const uint2 *mp) {
             const uint32_t n_mem = h ? (e.x & 0xFFu) : 0u;
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
 
 template <int K>
 __global__ __launch_bounds__(256) void k_pair_verify(
-    const uint32_t *__restrict__ cand, int cand_stride, const uint32_t *__restrict__ cand_cnt,
+    const uint32_t *__restrict__ cand, int cap, const uint32_t *__restrict__ cand_cnt,
     const uint32_t *__restrict__ planes32, const uint2 *__restrict__ list_tc,
     const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int tie,
     int32_t *__restrict__ redo_list, int32_t *__restrict__ n_redo,
@@ -838,15 +838,15 @@ __global__ __launch_bounds__(256) void k_pair_verify(
 #pragma unroll
     for (int c = 0; c < 3; ++c) { keep[c][0] = 0xFFFFFFFFu; keep[c][1] = 0xFFFFFFFFu; }
     const bool full_text = len == kTextCols;
-    const uint32_t *cp = cand + slot;
+    const uint32_t *cp = cand + (size_t)(slot >> 6) * ((size_t)(cap + 1) * 64) + (slot & 63);
 
     // candidates of round k: slots 2k and 2k+1 (an odd tail repeats the first).  Two-deep pipeline: the candidate
     // indices of round k+2 and the bit planes of round k+1 are requested before round k's automaton runs, so no
     // round waits on a load it issued itself.
     auto load_idx = [&](uint32_t k, uint32_t &a0, uint32_t &a1) {     // unconditional loads (clamped slot): no wait, no branch
         const bool v0 = 2 * k < cnt, v1 = 2 * k + 1 < cnt;
-        const uint32_t x0 = cp[(size_t)(v0 ? 2 * k : 0u) * cand_stride];
-        const uint32_t x1 = cp[(size_t)(v1 ? 2 * k + 1 : 0u) * cand_stride];
+        const uint32_t x0 = cp[(v0 ? 2 * k : 0u) << 6];
+        const uint32_t x1 = cp[(v1 ? 2 * k + 1 : 0u) << 6];
         a0 = v0 ? x0 : 0u;
         a1 = v1 ? x1 : a0;
     };

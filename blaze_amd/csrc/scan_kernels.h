@@ -1366,16 +1366,29 @@ __global__ __launch_bounds__(kClassifyThreads) void k_classify_packed(
     for (int k = 0; k < kClassifyRows; ++k) {
         if (!in[k]) bl[k] = 0;
         bool ok = wl_regular && !force_generic && bl[k] == kBcLen && len[k] >= kBcLen && len[k] <= kTextCols && max_ed <= kMaxK;
-        uint32_t c16 = 0, tlo = 0, thi = 0;
+        // Four characters per step: sel = their 2-bit codes, one per byte; v_perm turns the codes back into the letters
+        // they stand for ("ACTG"[code]) and the word is all ACGT iff that equals the word itself.  The codes of a word
+        // are squeezed into 8 bits with two shift-ors.  (The per-character form cost ~15 instructions per character,
+        // most of them half-rate compares; this kernel was issue bound on them.)
+        uint32_t bad = 0, tlo = 0, thi = 0;
+        const int over = len[k] - 16;                         // columns 16.. that belong to the text (0..4 for a regular row)
 #pragma unroll
-        for (int j = 0; j < kTextCols; ++j) {
-            const uint32_t c = rb[k].at(j);
-            ok = ok && (j >= len[k] || is_acgt(c));
-            const int i = j - off[k];
-            if (i >= 0 && i < kBcLen && j < len[k]) c16 |= base_code(c) << (2 * i);
-            if (j < 16) tlo |= base_code(c) << (2 * j);
-            else if (j < len[k]) thi |= base_code(c) << (2 * (j - 16));
+        for (int w = 0; w < kTextCols / 4; ++w) {
+            const uint32_t x = rb[k].w[w];
+            const uint32_t sel = (x >> 1) & 0x03030303u;
+            uint32_t diff = x ^ __builtin_amdgcn_perm(0x47544341u, 0x47544341u, sel);
+            uint32_t c = sel | (sel >> 6);
+            c = (c | (c >> 12)) & 0xFFu;
+            if (w < 4) tlo |= c << (8 * w);
+            else {
+                diff &= over >= 4 ? 0xFFFFFFFFu : ((1u << ((8 * over) & 31)) - 1u);
+                thi = c & ((1u << ((2 * over) & 31)) - 1u);
+            }
+            bad |= diff;
         }
+        ok = ok && bad == 0;
+        // the barcode's 16 columns start at off (host-checked: off + 16 <= len, so off <= 4 on a regular row)
+        const uint32_t c16 = (uint32_t)((((uint64_t)thi << 32) | tlo) >> ((2 * off[k]) & 63));
         regular[k] = ok; code[k] = c16;
         tc[k] = make_uint2(tlo, thi | ((uint32_t)len[k] << 8));
         lo[k] = 0; hi[k] = 0;

@@ -121,6 +121,7 @@ struct bz_engine {
     uint4 *d_grams = nullptr;          // 3-gram sets, two barcodes per uint4, padded to 32 barcodes
     uint32_t *d_planes32 = nullptr;    // hi-plane | lo-plane << 16 per barcode (verify gather)
     int32_t *d_bucket = nullptr;       // bucket table over the sorted codes' top bits
+    uint2 *d_bucket8 = nullptr;        //   and its one-gather form (k_classify_packed)
     int32_t *d_seed_tab[2] = {nullptr, nullptr};      // seed index, plan 0: pieces 5|5|6 (max_ed 2), plan 1: 8|8 (max_ed <= 1)
     int32_t *d_seed_members[2] = {nullptr, nullptr};  // per piece n_wl barcode indices grouped by the piece's code
     uint32_t *d_pair_bitmap = nullptr;  // pair-seed index: 6 x 65536-bit bucket occupancy (k_pair_candidates)
@@ -163,8 +164,8 @@ void free_whitelist(bz_handle h) {
     h->d_sorted_pairs = nullptr;
     hipFree(h->d_wl_bytes); hipFree(h->d_wl_off); hipFree(h->d_counts); hipFree(h->d_hist_partial);
     h->d_hist_partial = nullptr;
-    hipFree(h->d_grams); hipFree(h->d_planes32); hipFree(h->d_bucket);
-    h->d_grams = nullptr; h->d_planes32 = nullptr; h->d_bucket = nullptr;
+    hipFree(h->d_grams); hipFree(h->d_planes32); hipFree(h->d_bucket); hipFree(h->d_bucket8);
+    h->d_grams = nullptr; h->d_planes32 = nullptr; h->d_bucket = nullptr; h->d_bucket8 = nullptr;
     for (int k = 0; k < 2; ++k) {
         hipFree(h->d_seed_tab[k]); hipFree(h->d_seed_members[k]);
         h->d_seed_tab[k] = nullptr; h->d_seed_members[k] = nullptr;
@@ -514,6 +515,15 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
         HIP_TRY(hipMalloc(&h->d_bucket, (nb + 1) * sizeof(int32_t)));
         HIP_TRY(hipMemcpy(h->d_bucket, bucket.data(), (nb + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
         h->bucket_bits = bits;
+        {   // one-gather form: the bucket's first barcode {code, index | (more than one barcode) << 31}; index all ones = empty
+            std::vector<uint2> b8(nb);
+            for (int64_t b = 0; b < nb; ++b) {
+                const int32_t lo = bucket[b], hi = bucket[b + 1];
+                b8[b] = hi == lo ? make_uint2(0u, 0xFFFFFFFFu) : make_uint2(sorted[lo], (uint32_t)idx[lo] | (hi - lo > 1 ? 0x80000000u : 0u));
+            }
+            HIP_TRY(hipMalloc(&h->d_bucket8, nb * sizeof(uint2)));
+            HIP_TRY(hipMemcpy(h->d_bucket8, b8.data(), nb * sizeof(uint2), hipMemcpyHostToDevice));
+        }
 
         // filtered scan: 64-bit 3-gram set per barcode (padding = all ones: never passes), planes32
         const int64_t n_blk = (n + bz::kFilterBlock - 1) / bz::kFilterBlock;
@@ -659,7 +669,7 @@ int bz_assign_run(bz_handle h, int slot, int max_ed) {
         const dim3 cgrid((n + bz::kClassifyThreads * bz::kClassifyRows - 1) / (bz::kClassifyThreads * bz::kClassifyRows));
         if ((s.stride & 15) == 0 && s.stride >= 32)
             hipLaunchKernelGGL(bz::k_classify_packed, cgrid, dim3(bz::kClassifyThreads), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
-                               s.d_bcl, n, h->wl_regular, h->d_sorted_pairs, (int)h->n_wl, h->d_bucket, h->bucket_bits, h->shortcut,
+                               s.d_bcl, n, h->wl_regular, h->d_sorted_pairs, (int)h->n_wl, h->d_bucket, h->d_bucket8, h->bucket_bits, h->shortcut,
                                h->force_generic, max_ed, s.d_fast, (uint2 *)s.d_fast_tc, s.d_gen, s.d_counters, s.d_hit, s.d_ed, s.d_end, s.d_flags);
         else
             hipLaunchKernelGGL(bz::k_classify, dim3((n + bz::kClassifyThreads * bz::kClassifyRows - 1) / (bz::kClassifyThreads * bz::kClassifyRows)), dim3(bz::kClassifyThreads), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,

@@ -1337,8 +1337,8 @@ constexpr int kClassifyWaves = kClassifyThreads / 64;
 __global__ __launch_bounds__(kClassifyThreads) void k_classify_packed(
     const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
     const uint8_t *__restrict__ bc_off, const uint8_t *__restrict__ bc_len, int n, int wl_regular,
-    const uint2 *__restrict__ sorted_pairs, int n_wl, const int32_t *__restrict__ bucket_start, int bucket_bits,
-    int shortcut, int force_generic, int max_ed, int32_t *__restrict__ fast_list, uint2 *__restrict__ fast_tc,
+    const uint2 *__restrict__ sorted_pairs, int n_wl, const int32_t *__restrict__ bucket_start, const uint2 *__restrict__ bucket8,
+    int bucket_bits, int shortcut, int force_generic, int max_ed, int32_t *__restrict__ fast_list, uint2 *__restrict__ fast_tc,
     int32_t *__restrict__ gen_list, int32_t *__restrict__ counters, int32_t *__restrict__ hit_out,
     int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
     __shared__ int s_cnt[2][kClassifyRows][kClassifyWaves];   // [list][k][wave] -> exclusive offsets
@@ -1393,30 +1393,57 @@ __global__ __launch_bounds__(kClassifyThreads) void k_classify_packed(
         tc[k] = make_uint2(tlo, thi | ((uint32_t)len[k] << 8));
         lo[k] = 0; hi[k] = 0;
     }
-    uint2 pr[kClassifyRows];
+    // bucket8[b] = {code, index | multi << 31} of the bucket's first barcode (index 0xFFFFFFFF: empty bucket).  With ~4-8
+    // buckets per barcode almost every look-up ends at this ONE gather; only a row whose bucket holds several barcodes
+    // and whose code is not the first of them takes the lower-bound search (bucket bounds, then 1-2 probes).
+    int found[kClassifyRows];
     if (search) {
+        uint2 e[kClassifyRows];
+        bool need = false;
+#pragma unroll
+        for (int k = 0; k < kClassifyRows; ++k) e[k] = bucket8[(regular[k] && bucket_bits) ? code[k] >> (32 - bucket_bits) : 0u];
 #pragma unroll
         for (int k = 0; k < kClassifyRows; ++k) {
-            const uint32_t b = (regular[k] && bucket_bits) ? code[k] >> (32 - bucket_bits) : 0u;
-            const int l = bucket_start[b], h = bucket_start[b + 1];
-            lo[k] = regular[k] ? l : 0; hi[k] = regular[k] ? h : 0;
+            const bool occupied = regular[k] && e[k].y != 0xFFFFFFFFu;
+            found[k] = (occupied && e[k].x == code[k]) ? (int)(e[k].y & 0x7FFFFFFFu) : -1;
+            const bool more = occupied && found[k] < 0 && (e[k].y >> 31);
+            lo[k] = more ? 1 : 0; hi[k] = 0;
+            need = need || more;
         }
-        for (;;) {                                            // lower bound inside the (tiny) buckets, four rows per step
-            bool any = false;
-#pragma unroll
-            for (int k = 0; k < kClassifyRows; ++k) any = any || lo[k] < hi[k];
-            if (__builtin_amdgcn_ballot_w64(any) == 0) break;
-            uint32_t v[kClassifyRows];
-#pragma unroll
-            for (int k = 0; k < kClassifyRows; ++k) v[k] = sorted_pairs[lo[k] < hi[k] ? (lo[k] + hi[k]) >> 1 : 0].x;
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {
 #pragma unroll
             for (int k = 0; k < kClassifyRows; ++k) {
-                const int mid = (lo[k] + hi[k]) >> 1;
-                if (lo[k] < hi[k]) { if (v[k] < code[k]) lo[k] = mid + 1; else hi[k] = mid; }
+                const bool more = lo[k] != 0;
+                const uint32_t b = (more && bucket_bits) ? code[k] >> (32 - bucket_bits) : 0u;
+                const int l = bucket_start[b], h = bucket_start[b + 1];
+                lo[k] = more ? l : 0; hi[k] = more ? h : 0;
+            }
+            bool searched[kClassifyRows];
+#pragma unroll
+            for (int k = 0; k < kClassifyRows; ++k) searched[k] = lo[k] < hi[k];
+            for (;;) {                                        // lower bound inside the (tiny) buckets, four rows per step
+                bool any = false;
+#pragma unroll
+                for (int k = 0; k < kClassifyRows; ++k) any = any || lo[k] < hi[k];
+                if (__builtin_amdgcn_ballot_w64(any) == 0) break;
+                uint32_t v[kClassifyRows];
+#pragma unroll
+                for (int k = 0; k < kClassifyRows; ++k) v[k] = sorted_pairs[lo[k] < hi[k] ? (lo[k] + hi[k]) >> 1 : 0].x;
+#pragma unroll
+                for (int k = 0; k < kClassifyRows; ++k) {
+                    const int mid = (lo[k] + hi[k]) >> 1;
+                    if (lo[k] < hi[k]) { if (v[k] < code[k]) lo[k] = mid + 1; else hi[k] = mid; }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kClassifyRows; ++k) {
+                const uint2 pr = sorted_pairs[min(lo[k], n_wl - 1)];
+                if (searched[k] && lo[k] < n_wl && pr.x == code[k]) found[k] = (int)pr.y;
             }
         }
+    } else {
 #pragma unroll
-        for (int k = 0; k < kClassifyRows; ++k) pr[k] = sorted_pairs[min(lo[k], n_wl - 1)];
+        for (int k = 0; k < kClassifyRows; ++k) found[k] = -1;
     }
     int route[kClassifyRows], pos[kClassifyRows];
 #pragma unroll
@@ -1428,7 +1455,7 @@ __global__ __launch_bounds__(kClassifyThreads) void k_classify_packed(
         else if (!regular[k]) rt = 2;
         else {
             rt = 1;
-            if (search && lo[k] < n_wl && pr[k].x == code[k]) { hit = (int)pr[k].y; ed = 0; flags = kFlagExact; rt = 0; }
+            if (found[k] >= 0) { hit = found[k]; ed = 0; flags = kFlagExact; rt = 0; }
         }
         if (in[k]) { hit_out[r[k]] = hit; ed_out[r[k]] = (int8_t)ed; end_out[r[k]] = -1; flags_out[r[k]] = (uint8_t)flags; }
         const unsigned long long m1 = __builtin_amdgcn_ballot_w64(rt == 1), m2 = __builtin_amdgcn_ballot_w64(rt == 2);

@@ -78,6 +78,7 @@ struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t ev[7] = {};      // 0..4 run phases; 5, 6 = after k_pair_candidates / after k_pair_verify
     bool timed_pair = false;
+    bool tail_done = false;               // this run's scan already launched the rare-row scans (k_pair_tail)
     int64_t cap = 0;          // rows
     int cap_stride = 0;
     int64_t n = 0;
@@ -315,8 +316,12 @@ int launch_pair_two_kernels(bz_handle h, Slot &s) {
                        (const uint2 *)s.d_fast_tc, s.d_fast, s.d_counters, h->tie_rule, s.d_redo, s.d_counters + 2, s.d_hit, s.d_ed,
                        s.d_end, s.d_flags);
     if (h->profile) { HIP_TRY(hipEventRecord(s.ev[6], s.stream)); s.timed_pair = true; }
-    hipLaunchKernelGGL(bz::k_scan_filtered<2>, dim3(grid), dim3(block), 0, s.stream, (const uint4 *)h->d_grams, h->d_planes32, h->n_blk,
-                       (int)h->n_wl, s.d_ext, s.stride, s.d_len, s.d_redo, s.d_counters + 2, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+    // hand-over rows (ordered filtered scan) and irregular rows (byte-wise scan) in ONE launch; bz_assign_run skips its
+    // own k_scan_generic launch when tail_done is set
+    hipLaunchKernelGGL(bz::k_pair_tail, dim3(std::min(grid, 2 * h->n_cu)), dim3(256), 0, s.stream, (const uint4 *)h->d_grams, h->d_planes32,
+                       h->n_blk, (int)h->n_wl, h->d_wl_bytes, h->d_wl_off, s.d_ext, s.stride, s.d_len, s.d_off, s.d_bcl, s.d_redo,
+                       s.d_counters + 2, s.d_gen, s.d_counters + 1, 2, h->tie_rule, h->shortcut, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+    s.tail_done = true;
     return BZ_OK;
 }
 
@@ -662,6 +667,7 @@ int bz_assign_run(bz_handle h, int slot, int max_ed) {
     const bool prof = h->profile != 0;
     s.timed = prof;
     s.timed_pair = false;
+    s.tail_done = false;
     if (n == 0) { memset(s.h_counters, 0, 4 * sizeof(int32_t)); s.timed = false; s.ran = true; return BZ_OK; }
     int32_t *const next_counters = s.d_counters_base + (s.d_counters == s.d_counters_base ? 4 : 0);
     if (prof) HIP_TRY(hipEventRecord(s.ev[0], s.stream));
@@ -698,7 +704,7 @@ int bz_assign_run(bz_handle h, int slot, int max_ed) {
         HIP_TRY(hipGetLastError());
     }
     if (prof) HIP_TRY(hipEventRecord(s.ev[2], s.stream));
-    if (n) {
+    if (n && !s.tail_done) {
         hipLaunchKernelGGL(bz::k_scan_generic, dim3(std::min((n + 63) / 64, 16 * h->n_cu)), dim3(64), 0, s.stream, h->d_wl_bytes, h->d_wl_off, (int)h->n_wl,
                            s.d_ext, s.stride, s.d_len, s.d_off, s.d_bcl, s.d_gen, s.d_counters + 1, max_ed, h->tie_rule,
                            h->shortcut, s.d_hit, s.d_ed, s.d_end, s.d_flags);

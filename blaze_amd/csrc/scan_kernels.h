@@ -292,15 +292,14 @@ constexpr int kQCap = 32;                                         // FIFO entrie
 constexpr int kFilterBlock = 32;                                  // barcodes per filter block
 
 template <int K>
-__global__ __launch_bounds__(256) void k_scan_filtered(
+__device__ __forceinline__ void scan_filtered_block(
+    int block, int n_list, uint32_t (&fifo)[kQCap][256],
     const uint4 *__restrict__ grams, const uint32_t *__restrict__ planes32, int n_blk, int n_wl,
     const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
-    const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int tie,
+    const int32_t *__restrict__ list, int tie,
     int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
-    __shared__ uint32_t fifo[kQCap][256];                         // [entry][thread]: bank = thread, conflict free
-    const int n_list = *n_list_ptr;
     const int tid = threadIdx.x;
-    const int slot = blockIdx.x * blockDim.x + tid;
+    const int slot = block * 256 + tid;
     if ((slot & ~63) >= n_list) return;                           // whole wave idle (wave-uniform)
     const bool active = slot < n_list;
     const int r = list[active ? slot : n_list - 1];
@@ -409,6 +408,17 @@ __global__ __launch_bounds__(256) void k_scan_filtered(
         end_out[r] = (int8_t)(hit >= 0 ? hit_end : -1);
         flags_out[r] = (uint8_t)(hit == kHitAmbiguous ? kFlagAmbig : 0u);
     }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_scan_filtered(
+    const uint4 *__restrict__ grams, const uint32_t *__restrict__ planes32, int n_blk, int n_wl,
+    const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
+    const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int tie,
+    int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
+    __shared__ uint32_t fifo[kQCap][256];                         // [entry][thread]: bank = thread, conflict free
+    scan_filtered_block<K>(blockIdx.x, *n_list_ptr, fifo, grams, planes32, n_blk, n_wl, ext, ext_stride, ext_len, list, tie,
+                           hit_out, ed_out, end_out, flags_out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1199,14 +1209,14 @@ __device__ inline int dev_edit_distance(const uint8_t *a, int la, const uint8_t 
     return d > max_ed ? max_ed + 1 : d;
 }
 
-__global__ void k_scan_generic(const uint8_t *__restrict__ wl_bytes, const int64_t *__restrict__ wl_off, int n_wl,
+__device__ __forceinline__ void scan_generic_rows(int first, int step, int n_list,
+                               const uint8_t *__restrict__ wl_bytes, const int64_t *__restrict__ wl_off, int n_wl,
                                const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
                                const uint8_t *__restrict__ bc_off, const uint8_t *__restrict__ bc_len,
-                               const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int max_ed, int tie,
+                               const int32_t *__restrict__ list, int max_ed, int tie,
                                int shortcut, int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out,
                                int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
-    const int n_list = *n_list_ptr;
-    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_list; slot += gridDim.x * blockDim.x) {   // small persistent grid
+    for (int slot = first; slot < n_list; slot += step) {         // small persistent grid
     const int r = list[slot];
     const uint8_t *row = ext + (size_t)r * ext_stride;
     const int len = ext_len[r], off = bc_off[r], bl = bc_len[r];
@@ -1246,6 +1256,37 @@ __global__ void k_scan_generic(const uint8_t *__restrict__ wl_bytes, const int64
     end_out[r] = (int8_t)(ok ? hit_end : -1);
     flags_out[r] = (uint8_t)(kFlagGeneric | (hit == kHitAmbiguous ? kFlagAmbig : 0u));
     }
+}
+
+__global__ void k_scan_generic(const uint8_t *__restrict__ wl_bytes, const int64_t *__restrict__ wl_off, int n_wl,
+                               const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
+                               const uint8_t *__restrict__ bc_off, const uint8_t *__restrict__ bc_len,
+                               const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int max_ed, int tie,
+                               int shortcut, int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out,
+                               int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
+    scan_generic_rows(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, *n_list_ptr, wl_bytes, wl_off, n_wl, ext, ext_stride,
+                      ext_len, bc_off, bc_len, list, max_ed, tie, shortcut, hit_out, ed_out, end_out, flags_out);
+}
+
+// The two rare-row scans behind the pair-seeded kernels as ONE launch: hand-over rows (redo_list: candidate-list
+// overflow, short-text pools) through the ordered filtered scan, then irregular rows (gen_list) through the byte-wise
+// scan.  The two lists are disjoint and both are almost always empty, so what this saves is a launch and the idle gap
+// in front of it (~3-4 us of a ~100 us step).  Small persistent grid: workgroups stride over both lists.
+__global__ __launch_bounds__(256) void k_pair_tail(
+    const uint4 *__restrict__ grams, const uint32_t *__restrict__ planes32, int n_blk, int n_wl,
+    const uint8_t *__restrict__ wl_bytes, const int64_t *__restrict__ wl_off,
+    const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
+    const uint8_t *__restrict__ bc_off, const uint8_t *__restrict__ bc_len,
+    const int32_t *__restrict__ redo_list, const int32_t *__restrict__ n_redo_ptr,
+    const int32_t *__restrict__ gen_list, const int32_t *__restrict__ n_gen_ptr, int max_ed, int tie, int shortcut,
+    int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
+    __shared__ uint32_t fifo[kQCap][256];
+    const int n_redo = *n_redo_ptr, n_gen = *n_gen_ptr;
+    for (int b = blockIdx.x; b * 256 < n_redo; b += gridDim.x)
+        scan_filtered_block<2>(b, n_redo, fifo, grams, planes32, n_blk, n_wl, ext, ext_stride, ext_len, redo_list, tie,
+                               hit_out, ed_out, end_out, flags_out);
+    scan_generic_rows(blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, n_gen, wl_bytes, wl_off, n_wl, ext, ext_stride,
+                      ext_len, bc_off, bc_len, gen_list, max_ed, tie, shortcut, hit_out, ed_out, end_out, flags_out);
 }
 
 // far[i] = 1 iff every string of set B is at global edit distance >= min_ed from A[i]: the test of the empty-drop list,

@@ -132,6 +132,7 @@ struct bz_engine {
     int pair_cap = 0;                   //   candidate slots per row for the two-kernel form, 0 = use k_pair_stream
     int n_cu = 0;
     int bucket_bits = 0, n_blk = 0;
+    size_t cand_lds_set = 0;            // dynamic LDS bytes k_pair_candidates has been allowed so far
     uint32_t *d_sorted_codes = nullptr;
     uint2 *d_sorted_pairs = nullptr;      // {code, original index} sorted by code (k_classify_packed)
     int32_t *d_sorted_idx = nullptr;
@@ -306,7 +307,12 @@ int launch_pair_two_kernels(bz_handle h, Slot &s) {
     s.cand_stride = stride;
     const int64_t groups = (s.n + bz::kCandRowsPerBlock - 1) / bz::kCandRowsPerBlock;
     const int ga = (int)std::min<int64_t>(groups, (int64_t)2 * h->n_cu);          // persistent: 2 workgroups of 12 waves per CU (24 of its 32 wave slots)
-    hipLaunchKernelGGL(bz::k_pair_candidates, dim3(ga), dim3(bz::kCandWThreads), 0, s.stream, h->d_pair_bitmap, h->d_pair_tab8,
+    const size_t lst_bytes = (size_t)(h->pair_cap + 1) * bz::kCandRowsPerBlock * sizeof(uint16_t);   // the trip's lists in LDS
+    if (lst_bytes > h->cand_lds_set) {
+        HIP_TRY(hipFuncSetAttribute((const void *)bz::k_pair_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lst_bytes));
+        h->cand_lds_set = lst_bytes;
+    }
+    hipLaunchKernelGGL(bz::k_pair_candidates, dim3(ga), dim3(bz::kCandWThreads), lst_bytes, s.stream, h->d_pair_bitmap, h->d_pair_tab8,
                        h->d_pair_members, (int)h->n_wl, (const uint2 *)s.d_fast_tc, s.d_counters, s.d_cand, h->pair_cap,
                        s.d_cand_cnt);
     if (h->profile) HIP_TRY(hipEventRecord(s.ev[5], s.stream));

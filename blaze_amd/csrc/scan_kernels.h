@@ -650,8 +650,9 @@ constexpr int kPairTab = 65537;
 //   k_pair_candidates : one wave per (64 rows of the work list, pair).  Needs the text's 2-bit codes only (2 VGPRs,
 //       no bit-plane masks).  Probes its pair's LDS bitmap, turns occupied buckets into barcode indices through `tab8`
 //       (entry = {size | offset << 8, first member}: 96 % of the occupied buckets of a 5k list hold one barcode and
-//       need no second gather) and writes them to cand[slot / 64][s][slot % 64] (s-th candidate of list slot `slot`; tiles of 64 slots x (cap + 1) rows, s handed out by a
-//       per-row LDS counter shared by the row's six waves; k_pair_verify reads the matrix coalesced).
+//       need no second gather) and lists them in LDS (s-th candidate of a row, s handed out by a per-row LDS counter
+//       shared by the row's six waves); the lists go to cand[slot / 64][s][slot % 64] (tiles of 64 slots x (cap + 1)
+//       rows) 256 contiguous bytes per store, and k_pair_verify reads them the same way.
 //   k_pair_verify<K>  : lane = row.  Two candidates per round through the packed K-error automaton; of the accepting
 //       candidates only the two smallest indices per distance class are kept (all the ordered fold can consume, see
 //       k_pair_stream) and get their exact (ed, end) in at most six rounds at the end (a true match is met through 3-6
@@ -680,6 +681,7 @@ __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
     __shared__ uint32_t bm[kPairCount * kPairBmWords];
     __shared__ uint32_t row_cnt[kCandRowsPerBlock];
     __shared__ uint32_t seen[kCandSeen][kCandRowsPerBlock];       // per row: the last index listed per hash class (bank = row)
+    extern __shared__ uint16_t lst[];                             // [cap + 1][128]: the trip's candidate lists (host: n_wl < 65536), row `cap` = dump
     const int n_list = *n_list_ptr;
     const int tid = threadIdx.x;
     if ((int)blockIdx.x * kCandRowsPerBlock >= n_list) return;    // workgroup-uniform
@@ -699,7 +701,7 @@ __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
         const uint32_t tlo = t_next.x, thi = t_next.y & 0xFFu;    // 2-bit codes of the text, column j at bits 2j; 'A' padding past
         const uint64_t tc = (uint64_t)tlo | ((uint64_t)thi << 32);   // its end, which can only add candidates
         t_next = list_tc[min(slot + (int)gridDim.x * kCandRowsPerBlock, n_list - 1)];
-        uint32_t *out = cand + (size_t)(slot >> 6) * ((size_t)(cap + 1) * 64) + (slot & 63);   // the slot's column of its 64-slot tile
+        uint16_t *const out = lst + rg * 64 + lane;               // the row's column of the trip's lists in LDS
 
         // one bucket entry -> candidate slots (e.x = bucket size (saturating) | offset << 8, e.y = first member)
         // A true barcode is met through 3-6 of the pairs, i.e. by several of this row's waves: `seen` is a direct-mapped
@@ -711,7 +713,7 @@ __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
             if (*sp == idx) return;
             *sp = idx;
             const uint32_t base = atomicAdd(my_cnt, 1u);
-            out[min(base, (uint32_t)cap) << 6] = idx;                           // row `cap` of the tile is a dump row
+            out[min(base, (uint32_t)cap) * kCandRowsPerBlock] = (uint16_t)idx;  // row `cap` is a dump row
         };
         auto consume = [&](uint2 e, bool h, const uint2 *mp) {
             const uint32_t n_mem = h ? (e.x & 0xFFu) : 0u;
@@ -777,9 +779,20 @@ __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
             default: BZ_PAIR(2, 3, 5); break;
         }
 #undef BZ_PAIR
-        __syncthreads();                                          // the six waves of a row group are done with its counters
-        if (p_mine == 0 && active) { const uint32_t c = *my_cnt; cand_cnt[slot] = c > (uint32_t)cap ? kCandOverflow : c; }
-        __syncthreads();                                          // ... read before the next trip clears them
+        __syncthreads();                                          // the six waves of a row group are done with its lists
+        // Write-out: the lists go to the tile row by row, 64 slots x 4 bytes = 256 contiguous bytes per store (written
+        // straight from the lanes that found them, every store instruction touched up to 64 different lines).
+        // Wave w takes rows w / 2, w / 2 + 6, ... of tile w % 2.
+        {
+            const int t = wave & 1, row = t * 64 + lane, wslot = g * kCandRowsPerBlock + row;
+            const uint32_t c = row_cnt[row];
+            const uint32_t c_ok = (wslot < n_list && c <= (uint32_t)cap) ? c : 0u;
+            uint32_t *const tile = cand + (size_t)(wslot >> 6) * ((size_t)(cap + 1) * 64) + lane;
+            for (uint32_t q = (uint32_t)(wave >> 1); __builtin_amdgcn_ballot_w64(q < c_ok) != 0; q += kCandWaves / 2)
+                if (q < c_ok) tile[q << 6] = lst[q * kCandRowsPerBlock + row];
+            if (wave < 2 && wslot < n_list) cand_cnt[wslot] = c > (uint32_t)cap ? kCandOverflow : c;
+        }
+        __syncthreads();                                          // ... lists and counters read before the next trip reuses them
     }
 }
 

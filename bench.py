@@ -316,8 +316,8 @@ def main():
                 "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0, "traffic": None,
                 "kernel": "whole step (classify + scan + histogram)", "algorithmic_bytes_per_row": row_bytes,
                 "note": "algorithmic HBM bytes of one step (rows in + results out + the whitelist once) over the timed step: the "
-                        "step is nowhere near the HBM roof; at 1M rows (293K scored = 4.5 waves per SIMD) it is bound by the "
-                        "latency of dependent gathers and by VALU issue in the verify kernel"}
+                        "step is nowhere near the HBM roof; it is bound by instruction issue, LDS and L2 gathers in the "
+                        "candidate kernel and by VALU issue in the verify kernel (DESIGN.md 4.2)"}
 
     out = {
         "metric": "reads assigned/sec (whole node) vs 5k-cell whitelist; % int roofline",

@@ -925,15 +925,21 @@ __global__ __launch_bounds__(256) void k_pair_verify(
             }
         }
     }
-    // exact (ed, end) of the kept barcodes: compacted per lane, then as many wave-wide rounds as the fullest lane needs
-    int nkept = 0;
+    // Events of the kept barcodes.  On a 20-column text the class IS the edit distance (the lowest level that accepts in
+    // any column = the minimum over all end positions), and the fold needs the end index of the WINNER only: the kept
+    // indices become events as they are and one exact pass after the fold gives the winner's end.  (Every kept barcode
+    // used to get its exact (ed, end) first: as many wave-wide passes as the fullest lane kept, ~2.5 per wave.)  Shorter
+    // texts keep that path: their pool has no classes.
+    int nkept = 0, nacc = 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-            if (keep[c][t] != 0xFFFFFFFFu) events[nkept++][tid] = keep[c][t];
+        for (int t = 0; t < 2; ++t) {
+            if (keep[c][t] == 0xFFFFFFFFu) continue;
+            if (full_text) events[nacc++][tid] = (keep[c][t] << 7) | ((uint32_t)c << 5);
+            else events[nkept++][tid] = keep[c][t];
+        }
     }
-    int nacc = 0;
     for (int a = 0; __builtin_amdgcn_ballot_w64(a < nkept) != 0; ++a) {
         if (a < nkept) {
             const uint32_t idx = events[a][tid];
@@ -959,6 +965,11 @@ __global__ __launch_bounds__(256) void k_pair_verify(
     for (int a = 0; a < nacc; ++a) {
         const uint32_t v = events[a][tid];
         fold_update((int)((v >> 5) & 3u), (int)(v & 31u), (int)(v >> 7), best, hit, hit_end, done);
+    }
+    if (full_text && hit >= 0) {                                  // the winner's end index (its ed is `best`)
+        const uint32_t p = planes32[hit];
+        int ed_w;
+        exact_pair<K>(p & 0xFFFFu, p >> 16, XH, XL, len, tie, ed_w, hit_end);
     }
     hit_out[r] = hit >= 0 ? hit : -1;
     ed_out[r] = (int8_t)best;
@@ -1124,15 +1135,21 @@ __global__ __launch_bounds__(256) void k_pair_stream(
             }
         }
     }
-    // exact (ed, end) of the kept barcodes: compacted per lane, then as many wave-wide rounds as the fullest lane needs
-    int nkept = 0;
+    // Events of the kept barcodes.  On a 20-column text the class IS the edit distance (the lowest level that accepts in
+    // any column = the minimum over all end positions), and the fold needs the end index of the WINNER only: the kept
+    // indices become events as they are and one exact pass after the fold gives the winner's end.  (Every kept barcode
+    // used to get its exact (ed, end) first: as many wave-wide passes as the fullest lane kept, ~2.5 per wave.)  Shorter
+    // texts keep that path: their pool has no classes.
+    int nkept = 0, nacc = 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-            if (keep[c][t] != 0xFFFFFFFFu) events[nkept++][tid] = keep[c][t];
+        for (int t = 0; t < 2; ++t) {
+            if (keep[c][t] == 0xFFFFFFFFu) continue;
+            if (full_text) events[nacc++][tid] = (keep[c][t] << 7) | ((uint32_t)c << 5);
+            else events[nkept++][tid] = keep[c][t];
+        }
     }
-    int nacc = 0;
     for (int a = 0; __builtin_amdgcn_ballot_w64(a < nkept) != 0; ++a) {
         if (a < nkept) {
             const uint32_t idx = events[a][tid];
@@ -1158,6 +1175,11 @@ __global__ __launch_bounds__(256) void k_pair_stream(
     for (int a = 0; a < nacc; ++a) {
         const uint32_t v = events[a][tid];
         fold_update((int)((v >> 5) & 3u), (int)(v & 31u), (int)(v >> 7), best, hit, hit_end, done);
+    }
+    if (full_text && hit >= 0) {                                  // the winner's end index (its ed is `best`)
+        const uint32_t p = planes_of[hit];
+        int ed_w;
+        exact_pair<K>(p & 0xFFFFu, p >> 16, XH, XL, len, tie, ed_w, hit_end);
     }
     hit_out[r] = hit >= 0 ? hit : -1;
     ed_out[r] = (int8_t)best;

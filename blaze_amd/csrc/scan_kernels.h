@@ -1649,15 +1649,28 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_partial(const int32_t *__
     const int per = (((n + kHistBlocks - 1) / kHistBlocks) + 3) & ~3;     // rows per block, multiple of 4 (16-byte loads)
     const int lo = blockIdx.x * per, hi = min(n, lo + per);
     int assigned = 0;
-    for (int i = lo + 4 * threadIdx.x; i < hi; i += 4 * kHistThreads) {
-        if (i + 4 <= hi) {
-            const int4 h = *(const int4 *)(hit + i);
-            if (h.x >= 0) { atomicAdd(&s_bins[h.x], 1u); ++assigned; }
-            if (h.y >= 0) { atomicAdd(&s_bins[h.y], 1u); ++assigned; }
-            if (h.z >= 0) { atomicAdd(&s_bins[h.z], 1u); ++assigned; }
-            if (h.w >= 0) { atomicAdd(&s_bins[h.w], 1u); ++assigned; }
-        } else {
-            for (int k = i; k < hi; ++k) { const int h = hit[k]; if (h >= 0) { atomicAdd(&s_bins[h], 1u); ++assigned; } }
+    // four 16-byte loads in flight per thread before their LDS atomics (one after another, a block's 15.6K rows of a 1M-row
+    // step were four dependent load -> atomics rounds per thread)
+    constexpr int kU = 4;
+    for (int i0 = lo + 4 * threadIdx.x; i0 < hi; i0 += kU * 4 * kHistThreads) {
+        int4 h[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int i = i0 + u * 4 * kHistThreads;
+            h[u] = make_int4(-1, -1, -1, -1);
+            if (i + 4 <= hi) h[u] = *(const int4 *)(hit + i);
+            else if (i < hi) {                                    // the block's ragged end (at most once per block)
+                h[u].x = hit[i];
+                if (i + 1 < hi) h[u].y = hit[i + 1];
+                if (i + 2 < hi) h[u].z = hit[i + 2];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            if (h[u].x >= 0) { atomicAdd(&s_bins[h[u].x], 1u); ++assigned; }
+            if (h[u].y >= 0) { atomicAdd(&s_bins[h[u].y], 1u); ++assigned; }
+            if (h[u].z >= 0) { atomicAdd(&s_bins[h[u].z], 1u); ++assigned; }
+            if (h[u].w >= 0) { atomicAdd(&s_bins[h[u].w], 1u); ++assigned; }
         }
     }
     if (assigned) atomicAdd(&s_bins[n_wl], (uint32_t)assigned);

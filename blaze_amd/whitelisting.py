@@ -88,18 +88,15 @@ def get_bc_whitelist(raw_bc_count, full_bc_whitelist=None, exp_cells=None, count
     percentile_count_thres = high_sensitivity_threshold_calculation if high_sensitivity_mode \
         else default_count_threshold_calculation
 
-    whole_whitelist = []
+    # main.py:207-223: every line stripped, into a set (6.8M lines for the 10x lists: the strip runs in C here)
     if full_bc_whitelist.endswith('.zip'):
         with zipfile.ZipFile(full_bc_whitelist) as zf:
             assert len(zf.namelist()) == 1
             with io.TextIOWrapper(zf.open(zf.namelist()[0]), encoding="utf-8") as f:
-                for line in f:
-                    whole_whitelist.append(line.strip())
+                whole_whitelist = set(map(str.strip, f))
     else:
         with open(full_bc_whitelist, 'r') as f:
-            for line in f:
-                whole_whitelist.append(line.strip())
-    whole_whitelist = set(whole_whitelist)
+            whole_whitelist = set(map(str.strip, f))
     raw_bc_count = {k: v for k, v in raw_bc_count.items() if k in whole_whitelist}
 
     if force_cell_n:

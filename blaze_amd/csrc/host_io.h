@@ -17,6 +17,9 @@
 // the member boundaries are the reference's (one member per --batch-size reads per input file), the compressed bytes
 // themselves are not reproducible even in the reference (gzip header mtime).
 #pragma once
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -442,6 +445,37 @@ inline char comp(char c) {                                  // helper.reverse_co
     }
 }
 
+// dst[k] = comp(src[n - 1 - k]) / src[n - 1 - k]: the restrand of read_assignment.py:234-236 for one record.  32 bytes per
+// step where the host has AVX2 (byte reversal by shuffle + lane swap; the complement as an XOR: A<->T differ by 0x15,
+// C<->G by 0x04, both cases, every other byte unchanged as in helper.py:14-25), bytes through comp() otherwise.
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) inline void reverse_avx2(char *dst, const char *src, size_t n, bool complement) {
+    const __m256i rev = _mm256_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+    const __m256i lc = _mm256_set1_epi8(0x20), a = _mm256_set1_epi8('a'), t = _mm256_set1_epi8('t'), c = _mm256_set1_epi8('c'),
+                  g = _mm256_set1_epi8('g'), x_at = _mm256_set1_epi8(0x15), x_cg = _mm256_set1_epi8(0x04);
+    size_t k = 0;
+    for (; k + 32 <= n; k += 32) {
+        __m256i v = _mm256_loadu_si256((const __m256i *)(src + n - 32 - k));
+        v = _mm256_permute4x64_epi64(_mm256_shuffle_epi8(v, rev), 0x4E);           // bytes reversed across the 32
+        if (complement) {
+            const __m256i low = _mm256_or_si256(v, lc);
+            const __m256i at = _mm256_or_si256(_mm256_cmpeq_epi8(low, a), _mm256_cmpeq_epi8(low, t));
+            const __m256i cg = _mm256_or_si256(_mm256_cmpeq_epi8(low, c), _mm256_cmpeq_epi8(low, g));
+            v = _mm256_xor_si256(v, _mm256_or_si256(_mm256_and_si256(at, x_at), _mm256_and_si256(cg, x_cg)));
+        }
+        _mm256_storeu_si256((__m256i *)(dst + k), v);
+    }
+    for (; k < n; ++k) dst[k] = complement ? comp(src[n - 1 - k]) : src[n - 1 - k];
+}
+#endif
+inline void reverse_into(char *dst, const char *src, size_t n, bool complement) {
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) { reverse_avx2(dst, src, n, complement); return; }
+#endif
+    for (size_t k = 0; k < n; ++k) dst[k] = complement ? comp(src[n - 1 - k]) : src[n - 1 - k];
+}
+
 // Python slice of a string of length n: [:cut] when neg (cut < 0 given), [cut:] otherwise -> (start, len)
 inline void py_cut(uint32_t n, double polyT, uint32_t &start, uint32_t &len) {
     const double tr = polyT < 0 ? -std::floor(-polyT) : std::floor(polyT);       // int(): toward zero
@@ -459,6 +493,12 @@ inline void py_cut(uint32_t n, double polyT, uint32_t &start, uint32_t &len) {
 inline void format_batch(Chunk &ch, int b, const Job &job, const std::vector<char> &wl_bytes, const std::vector<int64_t> &wl_off) {
     const uint32_t lo = ch.batch_start[b], hi = ch.batch_start[b + 1];
     std::string text;
+    {
+        size_t bound = 0;                                    // the batch's records at most: no regrowth while appending
+        for (uint32_t r = lo; r < hi; ++r)
+            if (ch.bc[r].len && ch.hit[r] >= 0) bound += (size_t)ch.reads[r].seq.len + ch.reads[r].qual.len + ch.rid[r].len + 160;
+        text.reserve(bound);
+    }
     int64_t demul = 0;
     std::string umi;
     for (uint32_t r = lo; r < hi; ++r) {
@@ -501,11 +541,11 @@ inline void format_batch(Chunk &ch, int b, const Job &job, const std::vector<cha
         if (job.restrand && strand == '-') {
             const size_t at = text.size();
             text.resize(at + sl);
-            for (uint32_t k = 0; k < sl; ++k) text[at + k] = comp(sq[sl - 1 - k]);
+            reverse_into(&text[at], sq, sl, true);
             text.append("\n+\n");
             const size_t aq = text.size();
             text.resize(aq + ql);
-            for (uint32_t k = 0; k < ql; ++k) text[aq + k] = ql_p[ql - 1 - k];
+            reverse_into(&text[aq], ql_p, ql, false);
         } else {
             text.append(sq, sl); text.append("\n+\n"); text.append(ql_p, ql);
         }

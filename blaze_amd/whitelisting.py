@@ -88,16 +88,19 @@ def get_bc_whitelist(raw_bc_count, full_bc_whitelist=None, exp_cells=None, count
     percentile_count_thres = high_sensitivity_threshold_calculation if high_sensitivity_mode \
         else default_count_threshold_calculation
 
-    # main.py:207-223: every line stripped, into a set (6.8M lines for the 10x lists: the strip runs in C here)
+    # main.py:207-225: every line stripped, and the counted barcodes that are among them kept.  The reference builds a set
+    # of all 6.8M lines of a 10x list first (2.1 s, 600 MB); only membership of the counted barcodes is ever asked, so
+    # the lines are streamed against the (small) set of counted barcodes instead (0.66 s, strip in C)
+    counted = set(raw_bc_count)
     if full_bc_whitelist.endswith('.zip'):
         with zipfile.ZipFile(full_bc_whitelist) as zf:
             assert len(zf.namelist()) == 1
             with io.TextIOWrapper(zf.open(zf.namelist()[0]), encoding="utf-8") as f:
-                whole_whitelist = set(map(str.strip, f))
+                listed = counted.intersection(map(str.strip, f))
     else:
         with open(full_bc_whitelist, 'r') as f:
-            whole_whitelist = set(map(str.strip, f))
-    raw_bc_count = {k: v for k, v in raw_bc_count.items() if k in whole_whitelist}
+            listed = counted.intersection(map(str.strip, f))
+    raw_bc_count = {k: v for k, v in raw_bc_count.items() if k in listed}
 
     if force_cell_n:
         if force_cell_n > len(raw_bc_count):

@@ -1400,13 +1400,14 @@ __global__ void k_pair(const uint8_t *a, int la, const uint8_t *b, int lb, int m
 // over the code's top `bucket_bits` bits gives the (short) range, a lower-bound search inside it the
 // entry (duplicates -> first index in caller order).  2-3 dependent loads instead of log2(n_wl).
 constexpr int kTotStripes = 64;
-constexpr int kClassifyRows = 4;                              // rows per thread
-constexpr int kClassifyThreads = 1024;                        // 4096 rows per workgroup and ONE returned list atomic pair for them:
-                                                              // same-address returned atomics serialise at ~13 ns each, and 977
-                                                              // workgroups x 2 of them were most of this kernel's 32 us per 1M rows
+constexpr int kClassifyRows = 2;                              // rows per thread
+constexpr int kClassifyThreads = 1024;                        // 2048 rows per workgroup and ONE returned list atomic pair for them:
+                                                              // same-address returned atomics serialise at ~13 ns each.  Measured per
+                                                              // 1M rows (rows x threads): 4 x 1024 20.0 us, 2 x 1024 19.6, 1 x 1024
+                                                              // 23.4, 2 x 512 24.5, 2 x 256 35.6 (1953 workgroups x 2 atomics)
 constexpr int kClassifyWaves = kClassifyThreads / 64;
 
-// Staged form for the packed row layout: the four rows of a thread go through every step together (row bytes ->
+// Staged form for the packed row layout: the rows of a thread go through every step together (row bytes ->
 // bucket bounds -> search -> (code, index) pair -> stores), so a thread waits ~6 memory latencies instead of ~24.
 // The first form ran the rows one after another through divergent branches: 32 us per 1M rows with every wave
 // resident and nothing saturated.  sorted_pairs[i] = {code, original index}, sorted by code (stable).

@@ -318,7 +318,7 @@ int launch_pair_two_kernels(bz_handle h, Slot &s) {
     if (h->profile) HIP_TRY(hipEventRecord(s.ev[5], s.stream));
     const int block = 256;
     const int grid = (int)((s.n + block - 1) / block);
-    hipLaunchKernelGGL(bz::k_pair_verify<2>, dim3(grid), dim3(block), 0, s.stream, s.d_cand, h->pair_cap, s.d_cand_cnt, h->d_planes32,
+    hipLaunchKernelGGL(bz::k_pair_verify<2>, dim3((unsigned)((s.n + bz::kVerifyThreads - 1) / bz::kVerifyThreads)), dim3(bz::kVerifyThreads), 0, s.stream, s.d_cand, h->pair_cap, s.d_cand_cnt, h->d_planes32,
                        (const uint2 *)s.d_fast_tc, s.d_fast, s.d_counters, h->tie_rule, s.d_redo, s.d_counters + 2, s.d_hit, s.d_ed,
                        s.d_end, s.d_flags);
     if (h->profile) { HIP_TRY(hipEventRecord(s.ev[6], s.stream)); s.timed_pair = true; }

@@ -118,6 +118,47 @@ def test_irregular_rows(engine, oracle):
     assert t["rows_generic"] > 0 and t["rows_bitparallel"] > 0
 
 
+@pytest.mark.parametrize("scan_mode", **MODES)
+def test_bytes_past_the_text_are_ignored(engine, oracle, scan_mode):
+    """The C ABI gives a row ext_len bytes; whatever the caller's buffer holds behind them (here: random ACGT, N and
+    NUL) must not change a result.  Texts of 16..20 columns, barcode at offset 0..2."""
+    rows, wl = _synthetic(4000, 300, err=2.0, seed=17)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    for r in range(ext.shape[0]):
+        if bl[r] == 0:
+            continue
+        k = r % 5
+        if k == 1:
+            ext[r, :19] = ext[r, 1:20]; el[r] = 19; bo[r] = 1
+        elif k == 2:
+            ext[r, :16] = ext[r, 2:18]; el[r] = 16; bo[r] = 0
+        elif k == 3:
+            el[r] = 18
+        elif k == 4:
+            ext[r, :19] = ext[r, 1:20]; el[r] = 17; bo[r] = 1
+    clean = ext.copy()
+    clean[np.arange(ext.shape[1])[None, :] >= el[:, None]] = 0
+    wl_list = [w.tobytes() for w in wl]
+    want = _compare(engine, oracle, clean, el, bo, bl, wl_list, 2, scan_mode=scan_mode)
+    rng = np.random.default_rng(9)
+    dirty = clean.copy()
+    junk = np.frombuffer(b"ACGTN\0acgt", dtype=np.uint8)[rng.integers(0, 10, size=ext.shape)]
+    past = np.arange(ext.shape[1])[None, :] >= el[:, None]
+    dirty[past] = junk[past]
+    engine.set_option(_lib.BZ_OPT_SCAN_MODE, 0 if scan_mode == FUSED else scan_mode)
+    engine.set_option(_lib.BZ_OPT_PAIR_FUSED, int(scan_mode == FUSED))
+    try:
+        got = engine.assign(dirty, el, bo, bl, 2)
+    finally:
+        engine.set_option(_lib.BZ_OPT_SCAN_MODE, 0)
+        engine.set_option(_lib.BZ_OPT_PAIR_FUSED, 0)
+    for a, b, what in zip(want, got, ("hit", "ed", "end", "flags")):
+        if what == "flags":
+            a, b = a & FLAG_MASK, b & FLAG_MASK
+        bad = np.flatnonzero(a != b)
+        assert bad.size == 0, f"{what}: {bad.size} rows change with bytes behind the text, first row {bad[0]} (len {el[bad[0]]})"
+
+
 def test_irregular_whitelist(engine, oracle):
     """Whitelist with an N barcode, a 15-mer, an 18-mer and an empty string: generic kernel only."""
     rows, wl = _synthetic(800, 60, err=2.0, seed=14)

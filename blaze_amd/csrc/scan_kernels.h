@@ -710,8 +710,7 @@ __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
         // k_pair_verify ignores an index it already keeps).  ~14 -> ~10 candidates per row of a 5k-cell list.
         auto emit = [&](uint32_t idx) {
             uint32_t *const sp = &seen[idx & (kCandSeen - 1)][rg * 64 + lane];
-            if (*sp == idx) return;
-            *sp = idx;
+            if (atomicExch(sp, idx) == idx) return;              // one LDS exchange: of two waves listing an index at the same moment one sees the other's
             const uint32_t base = atomicAdd(my_cnt, 1u);
             out[min(base, (uint32_t)cap) * kCandRowsPerBlock] = (uint16_t)idx;  // row `cap` is a dump row
         };

@@ -84,7 +84,13 @@ def main():
             a.do_whitelisting = a.do_demultiplexing = False
             t0 = time.time(); bmain.main(a); t1 = time.time()
             a.do_bc_search, a.do_whitelisting = False, True
-            bmain.main(a); t2 = time.time()
+            if rep == "run" and "--profile-stage2" in sys.argv:
+                import cProfile, pstats
+                pr = cProfile.Profile(); pr.enable(); bmain.main(a); pr.disable()
+                pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(22)
+            else:
+                bmain.main(a)
+            t2 = time.time()
             a.do_whitelisting, a.do_demultiplexing = False, True
             bmain.main(a); t3 = time.time()
             out[rep] = {"stage1_s": t1 - t0, "stage2_s": t2 - t1, "stage3_s": t3 - t2, "total_s": t3 - t0,

@@ -608,11 +608,17 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
             HIP_TRY(hipMemcpy(h->d_pair_bitmap, bitmap.data(), bitmap.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(h->d_pair_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(h->d_pair_members, mem.data(), mem.size() * sizeof(uint2), hipMemcpyHostToDevice));
-            // two-kernel form: 8-byte table entries and a per-row candidate capacity of twice the expected number of
-            // chance candidates (162 probes x bucket occupancy) plus room for the true ones
-            const double chance = 162.0 * (double)n / 65536.0;
-            const int cap = (int)((2.0 * chance + 40.0) / 8.0) * 8;
-            if (cap <= 256) {
+            // two-kernel form: 8-byte table entries and a per-row candidate capacity of the expected number of candidates
+            // (131 probes x n / 65536 barcodes per bucket by chance, + 6 for a true barcode met through several pairs)
+            // + 5 sigma + 8: 48 at 5k cells, 64 at 10k, 88 at 20k, 144 at 40k (6.5 sigma or more once rounded).  A row above
+            // it (the rows of low-complexity whitelists) is handed to the ordered scan, which costs a whole-whitelist
+            // pass: milliseconds at 40k barcodes, so the capacity must not be tight (120 at 40k cells: 58 of 586K rows
+            // over it, step 0.82 -> 4.9 ms).  The capacity also sizes k_pair_candidates' lists in LDS: up to 93 rows two
+            // workgroups share a CU (the old 2 x chance + 40 = 136 rows at 20k cells allowed one, and configs[2] ran
+            // 17 % slower than with the lists in global memory).  Indices are 16 bits there: n < 48K.
+            const double chance = 131.0 * (double)n / 65536.0 + 6.0;
+            const int cap = ((int)std::ceil(chance + 5.0 * std::sqrt(chance) + 8.0) + 7) / 8 * 8;
+            if (n < 49152) {
                 std::vector<uint2> tab8((size_t)bz::kPairCount * 65536);
                 for (int p = 0; p < bz::kPairCount; ++p) {
                     const int32_t *t = tab.data() + (size_t)p * bz::kPairTab;

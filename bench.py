@@ -349,6 +349,15 @@ def main():
         eng.sync(0)
         hit, *_ = eng.fetch(0)
         base["gpu_matches_oracle_on_sample"] = bool(np.array_equal(hit[:n_chk], o_hit))
+        # the REAL reference (blaze.read_assignment.assign_read) cannot travel to the GPU box; its figure, measured in the
+        # build container by oracle/time_reference.py on 20k reads of this workload's shape, rides along as a quotation
+        ref_fn = os.path.join(ROOT, "profiles", "r01f_reference_cpu_B1.json")
+        if os.path.exists(ref_fn):
+            with open(ref_fn) as f:
+                b1 = json.load(f)
+            base["reference_quoted"] = {"reads_per_s_1_thread": b1["threads_1"]["reads_per_s"],
+                                        "reads_per_s_threads_8": b1["threads_8"]["reads_per_s"], "host_cpus": b1["host_cpus"],
+                                        "where": "build container, not this host; " + b1["what"], "file": "profiles/r01f_reference_cpu_B1.json"}
         out["cpu_baseline"] = base
     print(json.dumps(out), flush=True)
     plumb.barrier()

@@ -76,6 +76,18 @@ def _make_files(tmp_path, n, n_cells, seed, *, crlf=False, float_polyT=True, qui
     rows = synth.make_rows(n, cells, full, sub=0.01 * err, ins=0.005 * err, dele=0.005 * err, seed=seed + 3, umi_len=umi_len)
     ids = synth.read_ids(n, seed=seed + 4)
     recs = synth.fastq_records(n, ids, seed=seed + 5, median_len=300, min_len=60)
+    if quirks:      # restrand must reverse real qualities and complement ACGT/acgt only (helper.py:14-25): N, IUPAC, '-', lower case
+        odd = np.frombuffer(b"NnacgtRYKM-.*", dtype=np.uint8)
+        for j in range(n):
+            rid, seq, q = recs[j]
+            q = bytes(rng.integers(33, 75, size=len(q), dtype=np.uint8)).decode("ascii")
+            if j % 3 == 0:
+                b = bytearray(seq.encode())
+                at = rng.integers(0, len(b), size=max(1, len(b) // 9))
+                b_arr = np.frombuffer(bytes(b), dtype=np.uint8).copy()
+                b_arr[at] = odd[rng.integers(0, odd.size, size=at.size)]
+                seq = b_arr.tobytes().decode("ascii")
+            recs[j] = (rid, seq, q)
     s = lambda m, i: m[i].tobytes().decode("ascii")
     lines = [HEADER]
     for i in range(n):

@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libblaze_hip.so")
 
 BZ_OPT_TIE_RULE, BZ_OPT_SHORTCUT, BZ_OPT_FORCE_GENERIC, BZ_OPT_SCAN_MODE, BZ_OPT_PAIR_FUSED, BZ_OPT_PROFILE = 1, 2, 3, 4, 5, 6
-BZ_F_EXACT, BZ_F_BLANK, BZ_F_AMBIG, BZ_F_GENERIC = 1, 2, 4, 8
+BZ_F_EXACT, BZ_F_BLANK, BZ_F_AMBIG, BZ_F_GENERIC, BZ_F_INVALID = 1, 2, 4, 8, 16
+BZ_NOALLOC_MAX_ROWS = 262144
 BZ_EXT_MAX = 64
 BZ_E_MISMATCH = -6
 
@@ -23,7 +24,7 @@ EXPORTS = [
     "bz_assign_run", "bz_assign_fetch", "bz_slot_sync", "bz_slot_timing", "bz_sub_edit_distance",
     "bz_edit_distance", "bz_counts_reset", "bz_counts_get", "bz_comm_unique_id", "bz_comm_init",
     "bz_comm_allreduce_counts", "bz_comm_allreduce_f64", "bz_comm_destroy", "bz_valu_peak_probe", "bz_assign_files", "bz_far_from_all", "bz_putative_bc",
-    "bz_putative_bc_files", "bz_assign_files_from", "bz_fastq_count_reads",
+    "bz_putative_bc_files", "bz_assign_files_from", "bz_fastq_count_reads", "bz_assign_device_noalloc",
 ]
 
 
@@ -77,6 +78,7 @@ def load():
         "bz_putative_bc_files": ([ctypes.POINTER(p), i, ctypes.POINTER(cp), i, cp, i, i, i, i, i64, i, ctypes.POINTER(i64)], i),
         "bz_assign_files_from": ([ctypes.POINTER(p), i, ctypes.POINTER(cp), i, cp, i64, cp, i, i, i, i, i64, i, ctypes.POINTER(i64)], i),
         "bz_fastq_count_reads": ([cp, ctypes.POINTER(i64)], i),
+        "bz_assign_device_noalloc": ([p, p, i, p, p, p, i64, i, p, p, p, p, p], i),
         "bz_assign_files": ([ctypes.POINTER(p), i, ctypes.POINTER(cp), i, cp, cp, i, i, i, i, i64, i, ctypes.POINTER(i64)], i),
     }
     for name, (args, res) in sig.items():

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -111,6 +112,19 @@ struct S1Buf {
 
 }  // namespace
 
+// ---- scratch of the entry point that allocates nothing (bz_assign_device_noalloc) ---------------------------------
+// Work lists + counters of one run over at most BZ_NOALLOC_MAX_ROWS rows, in a file-scope device array: each GPU the
+// library runs on holds its own copy until the process ends.  In host code the NAME below is only a stand-in (passing it
+// to a kernel compiles and then faults): g_scratch_ptr[device], set once per device by scratch_init() through
+// hipGetSymbolAddress with that device current, is the address host code uses.
+constexpr size_t kNaRows = BZ_NOALLOC_MAX_ROWS;
+constexpr size_t kNaOffFast = 0, kNaOffGen = kNaOffFast + 4 * kNaRows, kNaOffRedo = kNaOffGen + 4 * kNaRows,
+                 kNaOffTc = kNaOffRedo + 4 * kNaRows, kNaOffCounters = kNaOffTc + 8 * kNaRows, kNaBytes = kNaOffCounters + 256;
+static __device__ __align__(256) unsigned char scratch[kNaBytes];
+constexpr int kMaxDevices = 64;
+static unsigned char *g_scratch_ptr[kMaxDevices] = {};
+static std::mutex g_scratch_mu;
+
 struct bz_engine {
     int device = 0;
     int tie_rule = 0, shortcut = 1, force_generic = 0, scan_mode = 0, pair_fused = 0, profile = 0;
@@ -158,6 +172,19 @@ namespace {
 int use(bz_handle h) {
     if (!h) return fail(BZ_E_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
+    return BZ_OK;
+}
+
+// once per device, with that device current: the device address of `scratch` on THIS GPU
+int scratch_init(int device) {
+    if (device < 0 || device >= kMaxDevices) return fail(BZ_E_LIMIT, "device %d beyond the %d this library keeps scratch for", device, kMaxDevices);
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    if (g_scratch_ptr[device]) return BZ_OK;
+    HIP_TRY(hipSetDevice(device));
+    void *ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return fail(BZ_E_HIP, "hipGetSymbolAddress(scratch) returned a null address on device %d", device);
+    g_scratch_ptr[device] = (unsigned char *)ptr;
     return BZ_OK;
 }
 
@@ -349,6 +376,71 @@ int fold_totals(bz_handle h, hipStream_t st) {
     return BZ_OK;
 }
 
+// One run over the rows a Slot (or a Slot-shaped view) describes: classify + shortcut -> scan by max_ed -> byte-wise
+// scan of the irregular rows -> per-barcode counts.  `lists_allowed` = the candidate-list form of the pair-seeded scan and
+// the privatised histogram may be used (both need buffers the engine allocates); without it the scan verifies straight
+// out of the buckets and the counts take global atomics.  The last kernel publishes the list counters to `publish` and
+// zeroes `next_counters`.
+int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed, int32_t *next_counters, int32_t *publish) {
+    const int n = (int)s.n;
+    const bool prof = s.timed;
+    const bool packed = (s.stride & 15) == 0 && s.stride >= 32;
+    if (prof) HIP_TRY(hipEventRecord(s.ev[0], s.stream));
+    {
+        const dim3 cgrid((n + bz::kClassifyThreads * bz::kClassifyRows - 1) / (bz::kClassifyThreads * bz::kClassifyRows));
+        if (packed)
+            hipLaunchKernelGGL(bz::k_classify_packed, cgrid, dim3(bz::kClassifyThreads), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
+                               s.d_bcl, n, h->wl_regular, h->d_sorted_pairs, (int)h->n_wl, h->d_bucket, h->d_bucket8, h->bucket_bits, h->shortcut,
+                               h->force_generic, max_ed, s.d_fast, (uint2 *)s.d_fast_tc, s.d_gen, s.d_counters, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+        else
+            hipLaunchKernelGGL(bz::k_classify, cgrid, dim3(bz::kClassifyThreads), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
+                               s.d_bcl, n, h->wl_regular, h->d_sorted_codes, h->d_sorted_idx, (int)h->n_wl, h->d_bucket, h->bucket_bits, h->shortcut,
+                               h->force_generic, max_ed, s.d_fast, s.d_gen, s.d_counters, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+        HIP_TRY(hipGetLastError());
+    }
+    if (prof) HIP_TRY(hipEventRecord(s.ev[1], s.stream));
+    if (h->wl_regular && !h->force_generic && max_ed <= bz::kMaxK) {
+        // product path for max_ed <= 2: pigeonhole seeds + verify (BZ_OPT_SCAN_MODE 0); mode 2 = exact 3-gram
+        // filter + verify over the whole whitelist; mode 1 = brute force (also what max_ed 3 takes: its
+        // seeds and 3-gram sets are too weak to pay)
+        // (event words hold the barcode index in 25 bits: larger whitelists take the filtered scan)
+        const bool seeded = (h->scan_mode == 0 || h->scan_mode == 3) && max_ed <= 2 && h->n_wl < ((int64_t)1 << 25);
+        const bool filtered = !seeded && h->scan_mode != 1 && max_ed <= 2;
+        switch (max_ed) {
+            case 0: if (seeded) launch_scan_seeded<0>(h, s); else if (filtered) launch_scan_filtered<0>(h, s); else launch_scan<0>(h, s); break;
+            case 1: if (seeded) launch_scan_seeded<1>(h, s); else if (filtered) launch_scan_filtered<1>(h, s); else launch_scan<1>(h, s); break;
+            case 2: if (seeded && h->scan_mode == 0 && packed) {
+                        if (h->pair_cap > 0 && !h->pair_fused && lists_allowed) { if (int rc = launch_pair_two_kernels(h, s)) return rc; }
+                        else launch_pair_stream(h, s);
+                    } else if (seeded) launch_scan_seeded<2>(h, s);
+                    else if (filtered) launch_scan_filtered<2>(h, s); else launch_scan<2>(h, s); break;
+            default: launch_scan<3>(h, s); break;
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    if (prof) HIP_TRY(hipEventRecord(s.ev[2], s.stream));
+    if (!s.tail_done) {
+        hipLaunchKernelGGL(bz::k_scan_generic, dim3(std::min((n + 63) / 64, 16 * h->n_cu)), dim3(64), 0, s.stream, h->d_wl_bytes, h->d_wl_off, (int)h->n_wl,
+                           s.d_ext, s.stride, s.d_len, s.d_off, s.d_bcl, s.d_gen, s.d_counters + 1, max_ed, h->tie_rule,
+                           h->shortcut, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+        HIP_TRY(hipGetLastError());
+    }
+    if (prof) HIP_TRY(hipEventRecord(s.ev[3], s.stream));
+    if (h->d_hist_partial && lists_allowed) {
+        uint32_t *const partial = h->d_hist_partial + (size_t)hist_slot * bz::kHistBlocks * h->n_wl;
+        hipLaunchKernelGGL(bz::k_hist_partial, dim3(bz::kHistBlocks), dim3(bz::kHistThreads), (size_t)(h->n_wl + 1) * sizeof(uint32_t), s.stream,
+                           s.d_hit, n, (int)h->n_wl, partial, h->d_counts);
+        hipLaunchKernelGGL(bz::k_hist_reduce, dim3(((int)h->n_wl + 255) / 256), dim3(256), 0, s.stream, partial, (int)h->n_wl, h->d_counts,
+                           s.d_counters, next_counters, publish);
+    } else {
+        hipLaunchKernelGGL(bz::k_histogram, dim3(std::min((n + 255) / 256, 1024)), dim3(256), 0, s.stream, s.d_hit, n, (int)h->n_wl, h->d_counts,
+                           s.d_counters, next_counters, publish);
+    }
+    HIP_TRY(hipGetLastError());
+    if (prof) HIP_TRY(hipEventRecord(s.ev[4], s.stream));
+    return BZ_OK;
+}
+
 size_t counts_bytes(int64_t n_wl) { return (size_t)(n_wl + 2 + 2 * bz::kTotStripes) * sizeof(unsigned long long); }
 
 }  // namespace
@@ -381,6 +473,7 @@ int bz_create(int device, bz_handle *out) {
     HIP_TRY(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) return fail(BZ_E_HIP, "device %d not present (%d visible): no GPU, no compute", device, n);
     HIP_TRY(hipSetDevice(device));
+    if (int rc = scratch_init(device)) return rc;
     bz_engine *h = new bz_engine();
     h->device = device;
     {
@@ -674,72 +767,50 @@ int bz_assign_run(bz_handle h, int slot, int max_ed) {
     if (h->n_wl < 0) return fail(BZ_E_STATE, "bz_set_whitelist has not been called");
     if (!s.staged) return fail(BZ_E_STATE, "slot %d has no staged rows", slot);
     if (max_ed < 0 || max_ed > BZ_EXT_MAX) return fail(BZ_E_ARG, "max_ed %d outside 0..%d", max_ed, BZ_EXT_MAX);
-    const int n = (int)s.n;
     // HIP events between the kernels cost ~6 us of idle GPU each: recorded only when BZ_OPT_PROFILE is on
-    const bool prof = h->profile != 0;
-    s.timed = prof;
+    s.timed = h->profile != 0;
     s.timed_pair = false;
     s.tail_done = false;
-    if (n == 0) { memset(s.h_counters, 0, 4 * sizeof(int32_t)); s.timed = false; s.ran = true; return BZ_OK; }
+    if (s.n == 0) { memset(s.h_counters, 0, 4 * sizeof(int32_t)); s.timed = false; s.ran = true; return BZ_OK; }
     int32_t *const next_counters = s.d_counters_base + (s.d_counters == s.d_counters_base ? 4 : 0);
-    if (prof) HIP_TRY(hipEventRecord(s.ev[0], s.stream));
-    if (n) {
-        const dim3 cgrid((n + bz::kClassifyThreads * bz::kClassifyRows - 1) / (bz::kClassifyThreads * bz::kClassifyRows));
-        if ((s.stride & 15) == 0 && s.stride >= 32)
-            hipLaunchKernelGGL(bz::k_classify_packed, cgrid, dim3(bz::kClassifyThreads), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
-                               s.d_bcl, n, h->wl_regular, h->d_sorted_pairs, (int)h->n_wl, h->d_bucket, h->d_bucket8, h->bucket_bits, h->shortcut,
-                               h->force_generic, max_ed, s.d_fast, (uint2 *)s.d_fast_tc, s.d_gen, s.d_counters, s.d_hit, s.d_ed, s.d_end, s.d_flags);
-        else
-            hipLaunchKernelGGL(bz::k_classify, dim3((n + bz::kClassifyThreads * bz::kClassifyRows - 1) / (bz::kClassifyThreads * bz::kClassifyRows)), dim3(bz::kClassifyThreads), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
-                           s.d_bcl, n, h->wl_regular, h->d_sorted_codes, h->d_sorted_idx, (int)h->n_wl, h->d_bucket, h->bucket_bits, h->shortcut,
-                           h->force_generic, max_ed, s.d_fast, s.d_gen, s.d_counters, s.d_hit, s.d_ed, s.d_end, s.d_flags);
-        HIP_TRY(hipGetLastError());
-    }
-    if (prof) HIP_TRY(hipEventRecord(s.ev[1], s.stream));
-    if (n && h->wl_regular && !h->force_generic && max_ed <= bz::kMaxK) {
-        // product path for max_ed <= 2: pigeonhole seeds + verify (BZ_OPT_SCAN_MODE 0); mode 2 = exact 3-gram
-        // filter + verify over the whole whitelist; mode 1 = brute force (also what max_ed 3 takes: its
-        // seeds and 3-gram sets are too weak to pay)
-        // (event words hold the barcode index in 25 bits: larger whitelists take the filtered scan)
-        const bool seeded = (h->scan_mode == 0 || h->scan_mode == 3) && max_ed <= 2 && h->n_wl < ((int64_t)1 << 25);
-        const bool filtered = !seeded && h->scan_mode != 1 && max_ed <= 2;
-        switch (max_ed) {
-            case 0: if (seeded) launch_scan_seeded<0>(h, s); else if (filtered) launch_scan_filtered<0>(h, s); else launch_scan<0>(h, s); break;
-            case 1: if (seeded) launch_scan_seeded<1>(h, s); else if (filtered) launch_scan_filtered<1>(h, s); else launch_scan<1>(h, s); break;
-            case 2: if (seeded && h->scan_mode == 0 && (s.stride & 15) == 0 && s.stride >= 32) {
-                        if (h->pair_cap > 0 && !h->pair_fused) { if (int rc = launch_pair_two_kernels(h, s)) return rc; }
-                        else launch_pair_stream(h, s);
-                    } else if (seeded) launch_scan_seeded<2>(h, s);
-                    else if (filtered) launch_scan_filtered<2>(h, s); else launch_scan<2>(h, s); break;
-            default: launch_scan<3>(h, s); break;
-        }
-        HIP_TRY(hipGetLastError());
-    }
-    if (prof) HIP_TRY(hipEventRecord(s.ev[2], s.stream));
-    if (n && !s.tail_done) {
-        hipLaunchKernelGGL(bz::k_scan_generic, dim3(std::min((n + 63) / 64, 16 * h->n_cu)), dim3(64), 0, s.stream, h->d_wl_bytes, h->d_wl_off, (int)h->n_wl,
-                           s.d_ext, s.stride, s.d_len, s.d_off, s.d_bcl, s.d_gen, s.d_counters + 1, max_ed, h->tie_rule,
-                           h->shortcut, s.d_hit, s.d_ed, s.d_end, s.d_flags);
-        HIP_TRY(hipGetLastError());
-    }
-    if (prof) HIP_TRY(hipEventRecord(s.ev[3], s.stream));
-    if (n) {
-        if (h->d_hist_partial) {
-            uint32_t *const partial = h->d_hist_partial + (size_t)slot * bz::kHistBlocks * h->n_wl;
-            hipLaunchKernelGGL(bz::k_hist_partial, dim3(bz::kHistBlocks), dim3(bz::kHistThreads), (size_t)(h->n_wl + 1) * sizeof(uint32_t), s.stream,
-                               s.d_hit, n, (int)h->n_wl, partial, h->d_counts);
-            hipLaunchKernelGGL(bz::k_hist_reduce, dim3(((int)h->n_wl + 255) / 256), dim3(256), 0, s.stream, partial, (int)h->n_wl, h->d_counts,
-                               s.d_counters, next_counters, s.h_counters_dev);
-        } else {
-            hipLaunchKernelGGL(bz::k_histogram, dim3(std::min((n + 255) / 256, 1024)), dim3(256), 0, s.stream, s.d_hit, n, (int)h->n_wl, h->d_counts,
-                               s.d_counters, next_counters, s.h_counters_dev);
-        }
-        HIP_TRY(hipGetLastError());
-    }
+    if (int rc = run_rows(h, s, slot, max_ed, /*lists_allowed=*/true, next_counters, s.h_counters_dev)) return rc;
     s.d_counters = next_counters;
-    if (prof) HIP_TRY(hipEventRecord(s.ev[4], s.stream));
     s.ran = true;
     return BZ_OK;
+}
+
+// The run of bz_assign_run over rows that are ALREADY in device memory, results left in device memory, with every work
+// list in the library's file-scope scratch array: no hipMalloc / hipFree / allocating call, asynchronous on `stream`.
+int bz_assign_device_noalloc(bz_handle h, const uint8_t *d_ext, int ext_stride, const uint8_t *d_ext_len, const uint8_t *d_bc_off,
+                             const uint8_t *d_bc_len, int64_t n, int max_ed, int32_t *d_hit, int8_t *d_ed, int8_t *d_end_idx,
+                             uint8_t *d_flags, void *stream) {
+    if (int rc = use(h)) return rc;
+    if (h->n_wl < 0) return fail(BZ_E_STATE, "bz_set_whitelist has not been called");
+    if (n < 0) return fail(BZ_E_ARG, "negative row count");
+    if (n > (int64_t)BZ_NOALLOC_MAX_ROWS)
+        return fail(BZ_E_LIMIT, "bz_assign_device_noalloc takes at most %d rows per call (got %lld): split the batch or use bz_assign_submit",
+                    BZ_NOALLOC_MAX_ROWS, (long long)n);
+    if (max_ed < 0 || max_ed > BZ_EXT_MAX) return fail(BZ_E_ARG, "max_ed %d outside 0..%d", max_ed, BZ_EXT_MAX);
+    if (ext_stride < 1 || ext_stride > BZ_EXT_MAX) return fail(BZ_E_LIMIT, "ext_stride %d outside 1..%d", ext_stride, BZ_EXT_MAX);
+    if (n == 0) return BZ_OK;
+    if (!d_ext || !d_ext_len || !d_bc_off || !d_bc_len || !d_hit || !d_ed || !d_end_idx || !d_flags) return fail(BZ_E_ARG, "null device array");
+    if ((ext_stride & 15) == 0 && ((uintptr_t)d_ext & 15) != 0) return fail(BZ_E_ARG, "d_ext must be 16-byte aligned for a stride that is a multiple of 16");
+    if (((uintptr_t)d_hit & 3) != 0) return fail(BZ_E_ARG, "d_hit must be 4-byte aligned");
+    unsigned char *const base = g_scratch_ptr[h->device];     // this GPU's copy of `scratch` (scratch_init, bz_create)
+    if (!base) return fail(BZ_E_STATE, "no scratch address for device %d", h->device);
+    Slot s;                                                    // a view: caller's arrays + the scratch lists, nothing owned
+    s.stream = stream ? (hipStream_t)stream : h->slot[0].stream;
+    s.n = n; s.stride = ext_stride;
+    s.d_ext = const_cast<uint8_t *>(d_ext); s.d_len = const_cast<uint8_t *>(d_ext_len);
+    s.d_off = const_cast<uint8_t *>(d_bc_off); s.d_bcl = const_cast<uint8_t *>(d_bc_len);
+    s.d_hit = d_hit; s.d_ed = d_ed; s.d_end = d_end_idx; s.d_flags = d_flags;
+    s.d_fast = (int32_t *)(base + kNaOffFast); s.d_gen = (int32_t *)(base + kNaOffGen); s.d_redo = (int32_t *)(base + kNaOffRedo);
+    s.d_fast_tc = base + kNaOffTc;
+    int32_t *const counters = (int32_t *)(base + kNaOffCounters);
+    s.d_counters = counters;
+    // the array keeps the last call's contents: the list counters must start at zero
+    HIP_TRY(hipMemsetAsync(counters, 0, 16 * sizeof(int32_t), s.stream));
+    return run_rows(h, s, 0, max_ed, /*lists_allowed=*/false, counters + 4, counters + 8);
 }
 
 static int start_fetch(Slot &s) {

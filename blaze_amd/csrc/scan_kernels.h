@@ -38,7 +38,7 @@ constexpr uint32_t kOne2 = 0x00010001u;
 constexpr int kHitNone = -1;
 constexpr int kHitAmbiguous = -2;
 
-constexpr unsigned kFlagExact = 1u, kFlagBlank = 2u, kFlagAmbig = 4u, kFlagGeneric = 8u;
+constexpr unsigned kFlagExact = 1u, kFlagBlank = 2u, kFlagAmbig = 4u, kFlagGeneric = 8u, kFlagInvalid = 16u;
 
 __device__ __forceinline__ uint32_t base_code(uint32_t c) { return (c >> 1) & 3u; }   // A0 C1 T2 G3
 __device__ __forceinline__ bool is_acgt(uint32_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
@@ -1424,12 +1424,17 @@ __global__ __launch_bounds__(kClassifyThreads) void k_classify_packed(
     const unsigned long long below = (1ull << lane) - 1ull;
     int r[kClassifyRows], len[kClassifyRows], off[kClassifyRows], bl[kClassifyRows];
     bool in[kClassifyRows];
+    uint32_t bad_row[kClassifyRows];                          // flags of a row without a barcode: blank, or blank | invalid
 #pragma unroll
     for (int k = 0; k < kClassifyRows; ++k) {
         r[k] = (blockIdx.x * kClassifyRows + k) * kClassifyThreads + threadIdx.x;
         in[k] = r[k] < n;
         const int rr = in[k] ? r[k] : 0;
         len[k] = ext_len[rr]; off[k] = bc_off[rr]; bl[k] = bc_len[rr];
+        // a row whose lengths do not fit its stride is never handed to a scan (the host entry points reject such a
+        // batch before any launch; rows that arrive in device memory are checked here): blank + BZ_F_INVALID
+        bad_row[k] = (in[k] && (len[k] > ext_stride || off[k] + bl[k] > len[k])) ? (kFlagBlank | kFlagInvalid) : kFlagBlank;
+        if (!in[k] || bad_row[k] != kFlagBlank) bl[k] = 0;
     }
     RowBytes rb[kClassifyRows];
 #pragma unroll
@@ -1441,7 +1446,6 @@ __global__ __launch_bounds__(kClassifyThreads) void k_classify_packed(
     int lo[kClassifyRows], hi[kClassifyRows];
 #pragma unroll
     for (int k = 0; k < kClassifyRows; ++k) {
-        if (!in[k]) bl[k] = 0;
         bool ok = wl_regular && !force_generic && bl[k] == kBcLen && len[k] >= kBcLen && len[k] <= kTextCols && max_ed <= kMaxK;
         // Four characters per step: sel = their 2-bit codes, one per byte; v_perm turns the codes back into the letters
         // they stand for ("ACTG"[code]) and the word is all ACGT iff that equals the word itself.  The codes of a word
@@ -1528,7 +1532,7 @@ __global__ __launch_bounds__(kClassifyThreads) void k_classify_packed(
         int hit = -1, rt = 0;
         uint32_t flags = 0;
         int ed = min(max_ed, 127);
-        if (bl[k] == 0) flags = kFlagBlank;
+        if (bl[k] == 0) flags = bad_row[k];
         else if (!regular[k]) rt = 2;
         else {
             rt = 1;
@@ -1574,13 +1578,16 @@ __global__ __launch_bounds__(kClassifyThreads) void k_classify(
     for (int k = 0; k < kClassifyRows; ++k) {
         const int r = (blockIdx.x * kClassifyRows + k) * kClassifyThreads + threadIdx.x;
         const bool in = r < n;
-        const int len = in ? ext_len[r] : 0, off = in ? bc_off[r] : 0, bl = in ? bc_len[r] : 0;
+        const int len = in ? ext_len[r] : 0, off = in ? bc_off[r] : 0;
+        int bl = in ? bc_len[r] : 0;
+        const bool bad_row = len > ext_stride || off + bl > len;   // see k_classify_packed
+        if (bad_row) bl = 0;
         int hit = -1;
         uint32_t flags = 0;
         int ed = min(max_ed, 127);
         int rt = 0;
         if (bl == 0) {
-            flags = kFlagBlank;
+            flags = bad_row ? (kFlagBlank | kFlagInvalid) : kFlagBlank;
         } else {
             bool regular = wl_regular && !force_generic && bl == kBcLen && len >= kBcLen && len <= kTextCols && max_ed <= kMaxK;
             uint32_t code = 0;

@@ -70,6 +70,9 @@ typedef struct bz_engine *bz_handle;
 #define BZ_F_BLANK 2u      /* empty putative_bc (`not row.putative_bc`, read_assignment.py:61) */
 #define BZ_F_AMBIG 4u      /* fold ended 'ambiguous' (read_assignment.py:82-88) */
 #define BZ_F_GENERIC 8u    /* row went through the generic DP kernel, not the bit-parallel one */
+#define BZ_F_INVALID 16u   /* row rejected on the device: ext_len > stride or barcode outside its extension (set together
+                              with BZ_F_BLANK; only rows handed over in device memory can carry it, host rows are
+                              rejected with BZ_E_ARG before any launch) */
 
 /* ---- library / device ------------------------------------------------------------------ */
 int bz_abi_version(void);
@@ -118,6 +121,26 @@ int bz_slot_sync(bz_handle h, int slot);
  * bit-parallel kernels, [2] rows scored by the generic kernel, [3] whitelist size, [4] rows the seeded
  * scan handed to the filtered scan (more than 8 near matches). */
 int bz_slot_timing(bz_handle h, int slot, float ms[8], int64_t counts[8]);
+
+/* ---- the entry point that allocates nothing ------------------------------------------------------------------
+ * NO COUNTERPART IN THE REFERENCE.  For callers that cannot call hipMalloc: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid allocation.  It is bz_assign_run for rows that already ARE in device memory
+ * (same layout as bz_assign_stage's arguments, but device pointers), results left in device memory (d_hit .. d_flags,
+ * n entries each), asynchronous on `stream` (a hipStream_t; NULL = the engine's slot-0 stream, wait with
+ * bz_slot_sync(h, 0)).  The kernels' work lists and counters (20 bytes per row) live in a file-scope device array of
+ * the library, 5.0 MiB per GPU for BZ_NOALLOC_MAX_ROWS rows, which each GPU holds until the process ends: the call
+ * performs no hipMalloc / hipFree / hipHostMalloc and no other allocating routine.  More rows than that:
+ * BZ_E_LIMIT, nothing launched.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two
+ * streams, two engines, two threads) RACE; calls on one stream are safe.  bz_set_whitelist must have been called (it is
+ * the set-up step and does allocate).  Results equal bz_assign_submit/wait's on the same rows (the max_ed 2 scan
+ * verifies straight out of the seed buckets instead of writing candidate lists); rows whose lengths do not fit are
+ * returned as BZ_F_BLANK | BZ_F_INVALID with hit -1 instead of an error (the host cannot see them).  The
+ * per-barcode histogram (bz_counts_get) is updated as by bz_assign_run.  d_ext must be 16-byte aligned when
+ * ext_stride is a multiple of 16. */
+#define BZ_NOALLOC_MAX_ROWS 262144
+int bz_assign_device_noalloc(bz_handle h, const uint8_t *d_ext, int ext_stride, const uint8_t *d_ext_len,
+                             const uint8_t *d_bc_off, const uint8_t *d_bc_len, int64_t n, int max_ed, int32_t *d_hit,
+                             int8_t *d_ed, int8_t *d_end_idx, uint8_t *d_flags, void *stream);
 
 /* Single pair on the device: the drop-in for fast_edit_distance.sub_edit_distance(a, b, max_ed)
  * -> (ed, end_idx) and edit_distance(a, b, max_ed) -> ed (read_assignment.py:1,72; main.py:24,250).

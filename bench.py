@@ -26,40 +26,61 @@ from blaze_amd.engine import Engine, device_info  # noqa: E402
 
 ALG_OPS_PER_PAIR = 340            # 20 text columns x 17 int32 bit-vector ops (Myers 1999)
 PEAK_INT32_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md)
+BRUTE_INSTR_PER_PAIR = 124.5      # k_scan_bitparallel<2>: 498 VALU instructions per four barcodes
 
 
-def file_allgather(tag, rank, world, value, timeout_s=120.0):
-    """Fallback plumbing when RCCL cannot be initialised: exchange small JSON values through /tmp."""
-    base = dist._rendezvous_path() + f".{tag}"
-    with open(f"{base}.{rank}.tmp", "w") as f:
-        json.dump(value, f)
-    os.replace(f"{base}.{rank}.tmp", f"{base}.{rank}")
-    out, t0 = [], time.time()
-    for r in range(world):
-        while not os.path.exists(f"{base}.{r}"):
-            if time.time() - t0 > timeout_s:
-                raise TimeoutError(f"rank {r} never wrote {tag}")
-            time.sleep(0.01)
-        for _ in range(100):
-            try:
-                with open(f"{base}.{r}") as f:
-                    out.append(json.load(f))
-                break
-            except (json.JSONDecodeError, OSError):
-                time.sleep(0.01)
-    return out
+def make_engine(device):
+    """The engine the bench measures: the C-ABI library on `device`.  BLAZE_AMD_BENCH_ENGINE=module:Class swaps in a
+    stand-in for the CPU test of the launch logic (tests/stub_engine.py); its line is labelled as such."""
+    spec = os.environ.get("BLAZE_AMD_BENCH_ENGINE")
+    if spec:
+        import importlib
+        mod, cls = spec.split(":")
+        return getattr(importlib.import_module(mod), cls)(device), True
+    return Engine(device), False
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with no launcher around it: start N fresh rank processes (one per GPU) BEFORE this
+    process touches a GPU, hand them RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, pass rank 0's JSON line through, and
+    fail if any rank fails.  (Under torchrun the ranks exist already and this is not used.)"""
+    import socket
+    import subprocess
+    import uuid
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    run_id = uuid.uuid4().hex[:12]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), BLAZE_AMD_RUN_ID=run_id, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    out0 = procs[0].communicate()[0]
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(codes):
+        sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
+        return 1
+    return 0
 
 
 class Plumbing:
-    """barrier / max / sum over ranks: RCCL through the C ABI, /tmp files if that fails."""
+    """barrier / max / sum over ranks: RCCL through the C ABI; the host-side socket hub (blaze_amd.dist.Hub, which also
+    carries the RCCL id) when RCCL cannot be initialised -- `kind` says which and why."""
 
-    def __init__(self, eng, rank, world):
-        self.rank, self.world, self.kind, self.eng, self.seq = rank, world, "local", eng, 0
+    def __init__(self, eng, rank, world, try_rccl=True):
+        self.rank, self.world, self.kind, self.eng = rank, world, "local", eng
         self.rccl = None
         self.hung = False
-        if world > 1:
+        self.hub = dist.get_hub() if world > 1 else None
+        if world > 1 and not try_rccl:
+            self.kind = "socket-hub (stand-in engine: no RCCL)"
+        elif world > 1:
             # RCCL's init is collective and cannot be cancelled: run it on a daemon thread with a deadline, so that a
-            # bootstrap that never completes costs 90 s and a file-fallback line instead of the whole measurement
+            # bootstrap that never completes costs 90 s and a hub line instead of the whole measurement
             import threading
             box = {}
 
@@ -71,30 +92,31 @@ class Plumbing:
             t = threading.Thread(target=init, daemon=True)
             t.start()
             t.join(float(os.environ.get("BLAZE_AMD_RCCL_INIT_TIMEOUT", "90")))
-            if "comm" in box:
+            mine = "rccl" if "comm" in box else (f"{type(box['err']).__name__}: {box['err']}" if "err" in box else "RCCL init did not finish in time")
+            self.hung = "comm" not in box and "err" not in box
+            # every rank must take the same route: one rank without RCCL sends all of them to the hub
+            states = self.hub.allgather(mine)
+            if all(x == "rccl" for x in states):
                 self.rccl, self.kind = box["comm"], "rccl"
-            elif "err" in box:
-                self.kind = f"file-fallback ({type(box['err']).__name__}: {box['err']})"[:200]
             else:
-                self.hung = True
-                self.kind = "file-fallback (RCCL init did not finish in time)"
-
-    def gather(self, value):
-        self.seq += 1
-        if self.world == 1:
-            return [value]
-        return file_allgather(f"g{self.seq}", self.rank, self.world, value)
+                why = next(x for x in states if x != "rccl")
+                self.kind = f"socket-hub (RCCL unavailable: {why})"[:240]
 
     def barrier(self):
         if self.rccl:
             self.rccl.barrier()
         elif self.world > 1:
-            self.gather(0)
+            self.hub.allgather(0)
 
     def max(self, x):
         if self.rccl:
             return self.rccl.allreduce_max_f64(x)
-        return max(self.gather(float(x)))
+        return max(self.hub.allgather(float(x))) if self.world > 1 else float(x)
+
+    def sum_counts(self, local):
+        if self.world == 1:
+            return local
+        return np.sum(np.asarray(self.hub.allgather([int(v) for v in local]), dtype=np.int64), axis=0)
 
 
 def cpu_baseline(ext, el, bo, bl, wl_bytes, max_ed, target_s=15.0):
@@ -115,39 +137,64 @@ def cpu_baseline(ext, el, bo, bl, wl_bytes, max_ed, target_s=15.0):
                        f"{int(((flag & 3) == 0).sum())} rows scored x {len(wl_bytes[1]) - 1} barcodes"), (hit, n)
 
 
-def attach_profile(roof, roof_brute):
-    """`traffic` (HBM bytes per launch) and `issued` (executed VALU lane-ops/s) come from the PMC
-    counters, which cannot be read inside this process: tools/profile.sh collects them with rocprofv3
-    (separate --pmc passes of this very command) and the newest committed profiles/*_pmc.json is read
-    back here.  gfx950 corrections per MI355X_MICROARCH.md 'HBM': FETCH_SIZE is doubled, WRITE_SIZE is
-    exact, both are KiB.  A roofline object that spans several kernels sums them."""
+def newest_profile(rows, cells, max_ed):
+    """The newest committed profiles/*_pmc.json taken on THIS workload (tools/profile.sh writes the workload into it;
+    files from round 1 carry none and were all taken on the default one)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc.json")))
-    if not files:
-        return
-    with open(files[-1]) as f:
-        prof = json.load(f)
-    for roof_obj, cls in ((roof, "product"), (roof_brute, "all_rows")):
-        traffic, insts, us, found = 0.0, 0.0, 0.0, 0
-        for kname in roof_obj["kernels"]:
-            ent = prof["kernels"].get("bz::" + kname, {}).get("classes", {})
-            c = ent.get(cls) or ent.get("all")
-            if not c or "avg_us" not in c:
-                continue
-            found += 1
-            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                traffic += (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-            insts += c.get("SQ_INSTS_VALU", 0.0)
-            us += c["avg_us"]
-        if found != len(roof_obj["kernels"]):
-            continue
-        roof_obj["profile"] = os.path.relpath(files[-1], ROOT)
-        if traffic:
-            roof_obj["traffic"] = traffic
-        if insts and us:
-            lane_ops = insts * 64.0 / (us * 1e-6) / 1e12
-            roof_obj["issued"] = {"valu_lane_Tops": lane_ops, "frac_of_peak": lane_ops / PEAK_INT32_TOPS,
-                                  "valu_instructions_per_launch": insts, "launch_us_in_profile": us}
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc.json")), reverse=True):
+        with open(fn) as f:
+            prof = json.load(f)
+        w = prof.get("workload") or {"rows": 1_000_000, "cells": 5000, "max_ed": 2}
+        if (w.get("rows"), w.get("cells"), w.get("max_ed")) == (rows, cells, max_ed):
+            return fn, prof
+    return None, None
+
+
+def profile_counters(prof, kernels, cls):
+    """Sum over `kernels` of the per-launch PMC means of dispatch class `cls`: executed VALU wave-instructions and
+    HBM bytes (gfx950 corrections per MI355X_MICROARCH.md 'HBM': FETCH_SIZE doubled, WRITE_SIZE exact, both KiB)."""
+    insts, traffic, us = 0.0, 0.0, 0.0
+    for k in kernels:
+        ent = prof["kernels"].get("bz::" + k, {}).get("classes", {})
+        c = ent.get(cls) or ent.get("all")
+        if not c or "SQ_INSTS_VALU" not in c or "avg_us" not in c:
+            return None
+        insts += c["SQ_INSTS_VALU"]
+        us += c["avg_us"]
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            traffic += (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    return insts, traffic or None, us
+
+
+def files_leg(a, threads=16):
+    """Step 3 over FILES on this host's cores (what a user of the drop-in sees): FASTQ + putative_bc.csv ->
+    demultiplexed FASTQ through assign_read's native host, plain and `.gz` (the reference's default output name,
+    config.py:45).  PCIe-, file-system- and host-CPU-inclusive; reported beside, never as, `value`."""
+    import tempfile
+    from blaze_amd import read_assignment as ra
+    n = a.file_reads
+    out = {"reads": n, "cells": 10_000, "umi_len": 10, "host_threads": threads,
+           "shape": "BASELINE configs[4]: 5v2-shaped rows (10-nt UMI) vs 10,000 cells, trim + restrand, 4 FASTQ files, page cache warm"}
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
+        fns, pc, wl, fq_bytes = synth.write_file_job(d, n, 10_000)
+        out["fastq_bytes_in"] = fq_bytes
+        kw = dict(fastq_fns=fns, putative_bc_csv=pc, whitelsit_csv=wl, max_ed=2, batchsize=1000, restrand=True, n_process=threads,
+                  host="native")
+        ra.assign_read(fastq_out=os.path.join(d, "warm.fastq"), **kw)          # page cache + engine warm
+        for name, suffix, reps in (("plain", ".fastq", 3), ("gz", ".fastq.gz", 1)):
+            best = None
+            for _ in range(reps):
+                fo = os.path.join(d, "out" + suffix)
+                t0 = time.perf_counter()
+                got = ra.assign_read(fastq_out=fo, **kw)
+                dt = time.perf_counter() - t0
+                if best is None or dt < best[0]:
+                    best = (dt, got, os.path.getsize(fo))
+            dt, got, size = best
+            out[name] = {"reads_per_s": n / dt, "s": dt, "fastq_in_GB_per_s": fq_bytes / dt / 1e9, "bytes_out": size,
+                         "assigned": int(got[0]), "total": int(got[1])}
+        out["gz"]["zlib_level"] = int(os.environ.get("BLAZE_AMD_GZ_LEVEL", "9"))
+    return out
 
 
 def main():
@@ -161,20 +208,34 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-two-slots", action="store_true",
                     help="skip the overlapped two-slot leg (tools/profile.sh: keeps every traced launch solo)")
+    ap.add_argument("--no-files", action="store_true", help="skip the step-3-over-files leg (N=1 only)")
+    ap.add_argument("--file-reads", type=int, default=200_000)
     a = ap.parse_args()
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
+    launched = "WORLD_SIZE" in os.environ
+    if not launched and a.gpus > 1:
+        # no launcher around us: become one, before anything here touches a GPU
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
     rank, world, local_rank = dist.env_rank_world()
+    if world != a.gpus:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to print a line "
+                         f"that would be read as {a.gpus} GPUs\n")
+        sys.exit(2)
+
     from blaze_amd.engine import device_count
-    n_dev = device_count()                    # a launcher may narrow each rank's view to its own GPU
+    stub = bool(os.environ.get("BLAZE_AMD_BENCH_ENGINE"))
+    n_dev = 1 if stub else device_count()     # a launcher may narrow each rank's view to its own GPU
     device = local_rank % max(n_dev, 1)
-    eng = Engine(device)
-    info = device_info(device)
+    eng, stub = make_engine(device)
+    info = {"stand-in": True} if stub else device_info(device)
     # librccl prints a version banner on stdout when it initialises: keep stdout for the one JSON line
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
     try:
-        plumb = Plumbing(eng, rank, world)
+        plumb = Plumbing(eng, rank, world, try_rccl=not stub)
     finally:
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
@@ -230,11 +291,7 @@ def main():
     value = a.rows * world / (dt / a.steps)
 
     # ---- the one collective: per-barcode counts + [assigned, total]
-    if plumb.rccl:
-        counts = plumb.rccl.allreduce_counts_on_device()
-    else:
-        local = eng.counts()
-        counts = np.sum(plumb.gather(local.tolist()), axis=0) if world > 1 else local
+    counts = plumb.rccl.allreduce_counts_on_device() if plumb.rccl else plumb.sum_counts(eng.counts())
     assigned_total, rows_total = int(counts[-2]), int(counts[-1])
 
     # ---- the engine's double buffering with resident rows: the same K steps alternating over both slots
@@ -263,20 +320,33 @@ def main():
     eng.set_option(_lib.BZ_OPT_SHORTCUT, 1)
     probe_ops, _ = eng.valu_peak_probe(20000)
 
-    # ---- boundary as the drop-in uses it: host arrays in, host arrays out, two slots in flight
-    #      (PCIe-inclusive; reported beside, never as, `value`)
-    n_e2e = max(4, min(a.steps, 10))
-    for k in range(2):
-        eng.submit(k, ext, el, bo, bl, a.max_ed)
-    eng.wait(0), eng.wait(1)
-    t0 = time.perf_counter()
-    for k in range(n_e2e):
-        if k >= 2:
-            eng.wait(k % 2)
-        eng.submit(k % 2, ext, el, bo, bl, a.max_ed)
-    for k in range(min(2, n_e2e)):
-        eng.wait((n_e2e + k) % 2)
-    pcie_rate = a.rows * n_e2e / (time.perf_counter() - t0)
+    # ---- the boundary as a caller with host arrays uses it: rows in host memory -> bz_assign_submit (H2D, kernels,
+    #      D2H) -> bz_assign_wait -> results in host memory, two slots in flight.  PCIe-inclusive: `value_boundary`,
+    #      reported beside, never as, `value`.  Twice: pageable numpy arrays (one extra host copy into the engine's
+    #      pinned staging) and arrays in pinned memory from bz_host_alloc (DMA straight from / to the caller's buffers).
+    def boundary_rate(submit, wait):
+        n_e2e = max(6, min(a.steps, 20))
+        for k in range(2):
+            submit(k)
+        wait(0), wait(1)
+        t0 = time.perf_counter()
+        for k in range(n_e2e):
+            if k >= 2:
+                wait(k % 2)
+            submit(k % 2)
+        for k in range(2):
+            wait((n_e2e + k) % 2)
+        return a.rows * n_e2e / (time.perf_counter() - t0)
+
+    pageable_rate = boundary_rate(lambda k: eng.submit(k, ext, el, bo, bl, a.max_ed), lambda k: eng.wait(k))
+    boundary = {"pageable_reads_per_s": pageable_rate}
+    pinned = getattr(eng, "pinned_rows", None)
+    if pinned is not None:
+        bufs = [pinned(ext, el, bo, bl) for _ in range(2)]
+        pinned_rate = boundary_rate(lambda k: eng.submit_pinned(k, bufs[k], a.max_ed), lambda k: eng.wait_pinned(k, bufs[k]))
+        for b in bufs:
+            b.free()
+        boundary["pinned_reads_per_s"] = pinned_rate
     eng.stage(0, ext, el, bo, bl)
     eng.sync(0)
 
@@ -286,49 +356,70 @@ def main():
             os._exit(0)                     # a thread is still inside RCCL's init: do not wait for it at exit
         return
 
-    def roofline(kernels, ms, t, note):
-        pairs = t["rows_bitparallel"] * a.cells
-        sec = ms * 1e-3
-        ach = pairs * ALG_OPS_PER_PAIR / sec / 1e12
-        return {"bound": "valu-int32", "achieved": ach, "peak": PEAK_INT32_TOPS, "unit": "Top/s",
-                "frac": ach / PEAK_INT32_TOPS, "traffic": None, "kernel": " + ".join(kernels), "kernels": kernels,
-                "launch_ms": ms, "algorithmic_ops_per_pair": ALG_OPS_PER_PAIR, "pairs_per_launch": pairs,
-                "rows_scored_per_launch": t["rows_bitparallel"], "pairs_per_s": pairs / sec, "note": note}
-
+    # ---- roofline objects.  The path is integer-VALU work: the roof is the int32 issue peak, and the
+    #      fraction is EXECUTED lane-ops per second over it -- never the pairs the seeds let the scan skip.
     row_bytes = ext.shape[1] + 3 + 7
     if a.max_ed == 2 and t_short["candidates_ms"] > 0:
         scan_kernels, scan_ms = ["k_pair_candidates", f"k_pair_verify<{a.max_ed}>"], t_short["candidates_ms"] + t_short["verify_ms"]
     else:
         scan_kernels, scan_ms = [f"k_scan_seeded<{a.max_ed}>"], t_short["scan_ms"]
-    roof = roofline(scan_kernels, scan_ms, t_short,
-                    "dominant kernels of the timed region (the scan = candidate generation + verify).  `achieved` prices every "
-                    "(row, barcode) pair the scan DECIDES at SURVEY 8d's 340 ops; the pair seeds prove ~99.8 % of them cannot "
-                    "match without running the automaton, so frac > 1 is algorithmic gain, not an issue rate: the "
-                    "executed-instruction rate is `issued` (rocprof SQ_INSTS_VALU), the all-pairs kernel is priced in "
-                    "roofline_bruteforce and the whole step against HBM in roofline_hbm")
-    roof_brute = roofline([f"k_scan_bitparallel<{a.max_ed}>"], t_all_brute["scan_ms"], t_all_brute,
-                          "all-pairs leg (BZ_OPT_SCAN_MODE 1, shortcut off): every pair runs the packed automaton, "
-                          "124.5 VALU instructions per pair against SURVEY 8d's 340-op Myers count")
+    prof_fn, prof = newest_profile(a.rows, a.cells, a.max_ed)
+    pairs_decided = t_short["rows_bitparallel"] * a.cells
+    roof = {"bound": "valu-int32", "achieved": None, "peak": PEAK_INT32_TOPS, "unit": "T lane-op/s", "frac": None, "traffic": None,
+            "kernel": " + ".join(scan_kernels), "kernels": scan_kernels, "launch_ms": scan_ms,
+            "rows_scored_per_launch": t_short["rows_bitparallel"],
+            "note": "dominant kernels of the timed region (candidate generation + verify).  achieved = executed VALU lane-ops per "
+                    "launch (rocprofv3 SQ_INSTS_VALU x 64 of the same launches on the same seeded workload, from `profile`) / "
+                    "the launch duration measured live here with HIP events; frac = achieved / the int32 issue peak.  What "
+                    "bounds these kernels instead of the VALU: instruction issue shared with scalar + LDS traffic and L2 "
+                    "gathers (DESIGN.md 4.2)"}
+    pc = profile_counters(prof, scan_kernels, "product") if prof else None
+    if pc:
+        insts, traffic, prof_us = pc
+        lane_ops = insts * 64.0
+        roof.update(achieved=lane_ops / (scan_ms * 1e-3) / 1e12, frac=lane_ops / (scan_ms * 1e-3) / 1e12 / PEAK_INT32_TOPS,
+                    traffic=traffic, profile=os.path.relpath(prof_fn, ROOT), valu_instructions_per_launch=insts,
+                    launch_us_in_profile=prof_us,
+                    algorithmic_speedup={"pairs_decided_per_launch": pairs_decided, "ops_per_pair_survey_8d": ALG_OPS_PER_PAIR,
+                                         "value": pairs_decided * ALG_OPS_PER_PAIR / lane_ops,
+                                         "note": "all-pairs work at SURVEY 8d's 340 ops per pair / lane-ops executed: what the pair "
+                                                 "seeds save, NOT a roofline fraction"})
+    brute_pairs = t_all_brute["rows_bitparallel"] * a.cells
+    brute_s = t_all_brute["scan_ms"] * 1e-3
+    brute_ach = brute_pairs * BRUTE_INSTR_PER_PAIR / brute_s / 1e12 if brute_s > 0 else None
+    roof_brute = {"bound": "valu-int32", "achieved": brute_ach, "peak": PEAK_INT32_TOPS, "unit": "T lane-op/s",
+                  "frac": brute_ach / PEAK_INT32_TOPS if brute_ach else None, "traffic": None,
+                  "kernel": f"k_scan_bitparallel<{a.max_ed}>", "launch_ms": t_all_brute["scan_ms"],
+                  "pairs_per_launch": brute_pairs, "pairs_per_s": brute_pairs / brute_s if brute_s > 0 else None,
+                  "instructions_per_pair": BRUTE_INSTR_PER_PAIR,
+                  "note": "all-pairs leg (BZ_OPT_SCAN_MODE 1, shortcut off): every (row, barcode) pair runs the packed automaton; "
+                          "priced at the 124.5 VALU instructions per pair the kernel's algorithm needs (498 per four barcodes, "
+                          "DESIGN.md 4.5), not at SURVEY 8d's 340-op Myers count, which is not a lower bound"}
+    pcb = profile_counters(prof, [f"k_scan_bitparallel<{a.max_ed}>"], "all_rows") if prof else None
+    if pcb:
+        roof_brute["traffic"] = pcb[1]
+        roof_brute["issued_frac_in_profile"] = pcb[0] * 64.0 / (pcb[2] * 1e-6) / 1e12 / PEAK_INT32_TOPS
     roof["measured_valu_ceiling_Tops"] = roof_brute["measured_valu_ceiling_Tops"] = probe_ops / 1e12
-    attach_profile(roof, roof_brute)
     step_bytes = a.rows * row_bytes + a.cells * 20
     roof_hbm = {"bound": "hbm", "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                 "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0, "traffic": None,
                 "kernel": "whole step (classify + scan + histogram)", "algorithmic_bytes_per_row": row_bytes,
                 "note": "algorithmic HBM bytes of one step (rows in + results out + the whitelist once) over the timed step: the "
-                        "step is nowhere near the HBM roof; it is bound by instruction issue, LDS and L2 gathers in the "
-                        "candidate kernel and by VALU issue in the verify kernel (DESIGN.md 4.2)"}
+                        "step is nowhere near the HBM roof (DESIGN.md 4.2)"}
 
+    best_boundary = max(boundary.values())
     out = {
         "metric": "reads assigned/sec (whole node) vs 5k-cell whitelist; % int roofline",
-        "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "value": value, "unit": "reads/s", "n_gpus": world, "n_gpus_requested": a.gpus, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u32", "dtype_note": "32-bit integer bit-vectors: two 16-bit automata per lane register", "data": "synthetic",
+        "dtype": "u32", "dtype_note": "32-bit integer bit-vectors: two 16-bit automata per lane register",
+        "data": "synthetic" if not stub else "STAND-IN ENGINE (launch-logic test, not a measurement)",
         "config": {"workload": f"configs[1]: synthetic 10x 3v3, {a.rows} nanopore-error reads per GPU vs "
                                f"{a.cells}-cell whitelist, max_ed {a.max_ed}, exact-match shortcut on",
                    "rows_per_gpu": a.rows, "cells": a.cells, "umi_len": 12, "errors": rows["params"],
                    "parallelism": f"read-sharded x{world}, whitelist replicated", "comm": plumb.kind,
-                   "device": info},
+                   "launcher": "torchrun / env" if launched and "BLAZE_AMD_RUN_ID" not in os.environ else ("bench.py --gpus" if world > 1 else "single process"),
+                   "devices_visible": n_dev, "ranks_per_device": -(-world // max(n_dev, 1)), "device": info},
         "assigned": assigned_total, "rows_counted": rows_total,
         "rows_scored_per_step": t_short["rows_bitparallel"], "rows_generic_per_step": t_short["rows_generic"],
         "rows_redone_per_step": t_short["rows_redo"],
@@ -339,10 +430,16 @@ def main():
                             "bruteforce": {"reads_per_s": t_all_brute["rows"] / (t_all_brute["total_ms"] * 1e-3),
                                            "scan_ms": t_all_brute["scan_ms"], "rows_scored": t_all_brute["rows_bitparallel"]}},
         "two_slots_in_flight": two_slots,
-        "pcie_inclusive_reads_per_s": pcie_rate,
+        "value_boundary": {"reads_per_s": best_boundary * world, "bytes_per_row": row_bytes,
+                           "GB_per_s_over_pcie": best_boundary * row_bytes / 1e9, **boundary,
+                           "note": "rows in host memory -> bz_assign_submit / bz_assign_wait -> results in host memory, two "
+                                   "slots in flight, per GPU x ranks; PCIe-inclusive (SURVEY 8d 'Timing'), never `value`"},
+        "pcie_inclusive_reads_per_s": best_boundary,
         "roofline": roof, "roofline_bruteforce": roof_brute, "roofline_hbm": roof_hbm,
     }
-    if not a.no_cpu_baseline and world == 1:
+    if not a.no_files and world == 1 and not stub:
+        out["value_files"] = files_leg(a)
+    if not a.no_cpu_baseline and world == 1 and not stub:
         eng.run(0, a.max_ed)                       # shortcut on again: the rows the oracle sample is checked against
         wl_packed = (np.ascontiguousarray(wl_ascii).reshape(-1), np.arange(a.cells + 1, dtype=np.int64) * 16)
         base, (o_hit, n_chk) = cpu_baseline(ext, el, bo, bl, wl_packed, a.max_ed)

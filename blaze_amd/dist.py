@@ -66,14 +66,125 @@ class TorchComm:
         self._td.barrier()
 
 
+def _rendezvous_key():
+    """What the ranks of one job share whatever launched them: (MASTER_ADDR, MASTER_PORT) and, when the launcher
+    gives one, its run id.  No pids: ranks need not have a common parent."""
+    run = os.environ.get("BLAZE_AMD_RUN_ID") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
+    return f"{os.environ.get('MASTER_ADDR', 'local')}_{os.environ.get('MASTER_PORT', '0')}" + (f"_{run}" if run else "")
+
+
 def _rendezvous_path():
-    key = f"{os.environ.get('MASTER_ADDR', 'local')}_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
-    return os.path.join(os.environ.get("BLAZE_AMD_RDZV_DIR", "/tmp"), f"blaze_amd_rccl_{key}.id")
+    return os.path.join(os.environ.get("BLAZE_AMD_RDZV_DIR", "/tmp"), f"blaze_amd_rccl_{_rendezvous_key()}.id")
 
 
-def exchange_unique_id(rank: int, make_id, timeout_s: float = 120.0) -> bytes:
-    """Single-node rendezvous for the 128-byte RCCL id: rank 0 writes it to a file named after
-    (MASTER_ADDR, MASTER_PORT, parent pid = the launcher), the other ranks poll for a fresh one."""
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("peer closed the rendezvous socket")
+        buf += chunk
+    return bytes(buf)
+
+
+class Hub:
+    """Host-side plumbing between the ranks of one node: rank 0 listens on MASTER_ADDR:(MASTER_PORT + 1)
+    (BLAZE_AMD_RDZV_PORT overrides; MASTER_PORT itself belongs to the launcher's store), the others connect.
+    It carries the 128-byte RCCL id, and -- when RCCL cannot be initialised -- the barrier / max / sum of a few scalars.
+    Never the data path.  Sockets die with their processes: nothing stale survives a crashed job."""
+
+    def __init__(self, rank, world, addr=None, port=None, timeout_s=120.0):
+        import socket
+        import struct
+        self.rank, self.world, self._struct = rank, world, struct
+        self.peers, self.endpoint = {}, "local"
+        if world == 1:
+            return
+        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(port or os.environ.get("BLAZE_AMD_RDZV_PORT") or int(os.environ.get("MASTER_PORT", "29500")) + 1)
+        self.endpoint = f"{addr}:{port}"
+        self.peers = {}
+        io_timeout = float(os.environ.get("BLAZE_AMD_HUB_TIMEOUT", "1800"))
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                srv.bind((addr, port))
+            except OSError:
+                srv.bind(("", port))                  # MASTER_ADDR is a name that is not an address of this host
+            srv.listen(max(world, 1))
+            srv.settimeout(timeout_s)
+            while len(self.peers) < world - 1:
+                c, _ = srv.accept()
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                c.settimeout(io_timeout)
+                r = struct.unpack("<i", _recv_exact(c, 4))[0]
+                self.peers[r] = c
+            srv.close()
+        else:
+            deadline = time.time() + timeout_s
+            while True:
+                c = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                try:
+                    c.connect((addr, port))
+                    break
+                except OSError:
+                    c.close()
+                    if time.time() > deadline:
+                        raise TimeoutError(f"rank {rank}: no rendezvous hub at {addr}:{port} after {timeout_s}s")
+                    time.sleep(0.05)
+            c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            c.settimeout(io_timeout)
+            c.sendall(struct.pack("<i", rank))
+            self.peers[0] = c
+
+    def _send(self, sock, payload):
+        sock.sendall(self._struct.pack("<q", len(payload)) + payload)
+
+    def _recv(self, sock):
+        return _recv_exact(sock, self._struct.unpack("<q", _recv_exact(sock, 8))[0])
+
+    def allgather_bytes(self, payload: bytes):
+        """Every rank's payload, in rank order, on every rank."""
+        if self.world == 1:
+            return [payload]
+        if self.rank == 0:
+            parts = [payload] + [self._recv(self.peers[r]) for r in range(1, self.world)]
+            for r in range(1, self.world):
+                for part in parts:
+                    self._send(self.peers[r], part)
+            return parts
+        self._send(self.peers[0], payload)
+        return [self._recv(self.peers[0]) for _ in range(self.world)]
+
+    def allgather(self, value):
+        import json
+        return [json.loads(b.decode()) for b in self.allgather_bytes(json.dumps(value).encode())]
+
+    def close(self):
+        for c in self.peers.values():
+            try:
+                c.close()
+            except OSError:
+                pass
+        self.peers = {}
+
+
+_hub = None
+
+
+def get_hub():
+    """This process's hub (created on first use from RANK / WORLD_SIZE / MASTER_*)."""
+    global _hub
+    if _hub is None:
+        rank, world, _ = env_rank_world()
+        _hub = Hub(rank, world)
+    return _hub
+
+
+def exchange_unique_id_file(rank: int, make_id, timeout_s: float = 120.0) -> bytes:
+    """Second channel for the 128-byte RCCL id when the hub's port cannot be used: rank 0 writes it to a file named
+    after (MASTER_ADDR, MASTER_PORT[, run id]); the other ranks poll for a fresh one."""
     path = _rendezvous_path()
     if rank == 0:
         uid = make_id()
@@ -86,7 +197,7 @@ def exchange_unique_id(rank: int, make_id, timeout_s: float = 120.0) -> bytes:
     while True:
         try:
             st = os.stat(path)
-            if st.st_size == 128 and st.st_mtime >= start - 600:
+            if st.st_size == 128 and st.st_mtime >= start - 120:
                 with open(path, "rb") as f:
                     return f.read()
         except FileNotFoundError:
@@ -94,6 +205,12 @@ def exchange_unique_id(rank: int, make_id, timeout_s: float = 120.0) -> bytes:
         if time.time() - start > timeout_s:
             raise TimeoutError(f"no RCCL id at {path} after {timeout_s}s")
         time.sleep(0.02)
+
+
+def exchange_unique_id(rank: int, make_id, timeout_s: float = 120.0) -> bytes:
+    """Single-node rendezvous for the 128-byte RCCL id: through the hub (rank 0 makes it, everyone gets it)."""
+    hub = get_hub()
+    return hub.allgather_bytes(make_id() if rank == 0 else b"")[0]
 
 
 class RcclComm:
@@ -106,11 +223,6 @@ class RcclComm:
         uid = exchange_unique_id(rank, Engine.comm_unique_id)
         engine.comm_init(uid, world, rank)
         self.barrier()
-        if rank == 0:
-            try:
-                os.remove(_rendezvous_path())
-            except OSError:
-                pass
 
     def allreduce_counts_on_device(self):
         """In place on the GPU: per-barcode histogram + [assigned, total]."""
@@ -118,12 +230,8 @@ class RcclComm:
         return self.engine.counts()
 
     def allreduce_sum_i64(self, arr):
-        a = np.asarray(arr, dtype=np.int64)
-        out = np.empty_like(a)
-        flat, res = a.reshape(-1), out.reshape(-1)
-        for lo in range(0, flat.size, 64):          # small host vectors only; exact below 2^53
-            res[lo:lo + 64] = self.engine.comm_allreduce_f64(flat[lo:lo + 64].astype(np.float64), "sum").astype(np.int64)
-        return out
+        """Exact int64 sum of a host vector of any length (ncclInt64 on the device, one call)."""
+        return self.engine.comm_allreduce_i64(arr)
 
     def allreduce_max_f64(self, x):
         return float(self.engine.comm_allreduce_f64([float(x)], "max")[0])

@@ -31,6 +31,34 @@ def pack_whitelist(whitelist):
     return data, off
 
 
+class PinnedRows:
+    """One batch's input and result arrays as numpy views of ONE pinned host allocation (bz_host_alloc): what
+    bz_assign_submit_pinned DMAs from and into.  Fill `ext / ext_len / bc_off / bc_len`, read `hit / ed / end / flags`."""
+
+    def __init__(self, n: int, stride: int):
+        self._L = _lib.load()
+        self.n, self.stride = int(n), int(stride)
+        sizes = [n * stride, n, n, n, 4 * n, n, n, n]
+        offs = np.concatenate([[0], np.cumsum([(b + 255) // 256 * 256 for b in sizes])])
+        self._ptr = ctypes.c_void_p()
+        check(self._L.bz_host_alloc(ctypes.byref(self._ptr), int(offs[-1])))
+        raw = (ctypes.c_uint8 * int(offs[-1])).from_address(self._ptr.value)
+        buf = np.frombuffer(raw, dtype=np.uint8)
+        v = [buf[offs[k]:offs[k] + sizes[k]] for k in range(8)]
+        self.ext, self.ext_len, self.bc_off, self.bc_len = v[0].reshape(n, stride), v[1], v[2], v[3]
+        self.hit, self.ed, self.end, self.flags = v[4].view(np.int32), v[5].view(np.int8), v[6].view(np.int8), v[7]
+
+    def fill(self, ext, ext_len, bc_off, bc_len):
+        self.ext[...], self.ext_len[...], self.bc_off[...], self.bc_len[...] = ext, ext_len, bc_off, bc_len
+        return self
+
+    def free(self):
+        if self._ptr:
+            self.ext = self.ext_len = self.bc_off = self.bc_len = self.hit = self.ed = self.end = self.flags = None
+            self._L.bz_host_free(self._ptr)
+            self._ptr = ctypes.c_void_p()
+
+
 class Engine:
     def __init__(self, device: int = 0, tie_rule: int = TIE_LEFTMOST):
         self._L = _lib.load()
@@ -117,6 +145,22 @@ class Engine:
         self.submit(slot, ext, ext_len, bc_off, bc_len, max_ed)
         return self.wait(slot)
 
+    # rows and results in pinned host memory: no staging copy on either side of the PCIe transfers
+    def pinned_rows(self, ext, ext_len, bc_off, bc_len):
+        ext, el, bo, bl = self._rows(ext, ext_len, bc_off, bc_len)
+        return PinnedRows(ext.shape[0], max(ext.shape[1], 1)).fill(ext, el, bo, bl)
+
+    def submit_pinned(self, slot, rows: "PinnedRows", max_ed: int):
+        check(self._L.bz_assign_submit_pinned(self._h, slot, _ptr(rows.ext), rows.stride, _ptr(rows.ext_len), _ptr(rows.bc_off),
+                                              _ptr(rows.bc_len), rows.n, int(max_ed), _ptr(rows.hit), _ptr(rows.ed), _ptr(rows.end),
+                                              _ptr(rows.flags)))
+        self._pending[slot] = rows.n
+
+    def wait_pinned(self, slot, rows: "PinnedRows"):
+        check(self._L.bz_assign_wait(self._h, slot, None, None, None, None))
+        self._pending[slot] = None
+        return rows.hit, rows.ed, rows.end, rows.flags
+
     # stage / run / fetch, for callers that keep rows resident (bench.py)
     def stage(self, slot, ext, ext_len, bc_off, bc_len):
         ext, el, bo, bl = self._rows(ext, ext_len, bc_off, bc_len)
@@ -185,6 +229,12 @@ class Engine:
     def comm_allreduce_f64(self, values, op: str = "sum"):
         arr = np.ascontiguousarray(values, dtype=np.float64).copy()
         check(self._L.bz_comm_allreduce_f64(self._h, arr.ctypes.data, arr.size, 1 if op == "max" else 0))
+        return arr
+
+    def comm_allreduce_i64(self, values):
+        arr = np.ascontiguousarray(values, dtype=np.int64).copy()
+        if arr.size:
+            check(self._L.bz_comm_allreduce_i64(self._h, arr.ctypes.data, arr.size))
         return arr
 
     def comm_destroy(self):

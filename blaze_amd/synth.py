@@ -177,3 +177,36 @@ def fastq_records(n: int, ids, seed: int = 5, median_len: int = 900, sigma: floa
 
 def fastq_text(recs) -> str:
     return "".join(f"@{rid} runid=synthetic\n{seq}\n+\n{q}\n" for rid, seq, q in recs)
+
+
+def write_file_job(d, n, n_cells, umi_len=10, n_files=4, seed=3, median_len=900):
+    """Step-3 inputs on disk in BASELINE configs[4]'s shape: `n_files` FASTQ files of log-normal read
+    lengths, their putative_bc.csv and a `-1`-suffixed whitelist.  Returns (fastq_fns, csv, whitelist, fastq_bytes)."""
+    import os
+    full = full_whitelist_codes(400_000, seed=1)
+    cells = cell_whitelist_codes(n_cells, full, seed=2)
+    rows = make_rows(n, cells, full, umi_len=umi_len, seed=seed)
+    ids = read_ids(n, seed=4)
+    rng = np.random.Generator(np.random.PCG64(5))
+    lens = np.maximum(150, rng.lognormal(np.log(median_len), 0.6, size=n).astype(np.int64))
+    pool = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(lens.max()) + (1 << 20))].tobytes()
+    starts = rng.integers(0, 1 << 20, size=n)
+    with open(os.path.join(d, "putative_bc.csv"), "w") as f:
+        f.write(csv_text(rows, ids))
+    fns, per = [], -(-n // n_files)
+    total_bytes = 0
+    for k in range(n_files):
+        fn = os.path.join(d, f"reads_{k}.fastq")
+        with open(fn, "wb") as f:
+            for i in range(k * per, min(n, (k + 1) * per)):
+                L = int(lens[i])
+                s = int(starts[i])
+                rec = b"@" + ids[i].encode() + b" runid=synthetic\n" + pool[s:s + L] + b"\n+\n" + b"I" * L + b"\n"
+                f.write(rec)
+                total_bytes += len(rec)
+        fns.append(fn)
+    wl = os.path.join(d, "whitelist.csv")
+    with open(wl, "w") as f:
+        for w in codes_to_bytes(cells):
+            f.write(w.tobytes().decode() + "-1\n")
+    return fns, os.path.join(d, "putative_bc.csv"), wl, total_bytes

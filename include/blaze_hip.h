@@ -109,6 +109,18 @@ int bz_assign_submit(bz_handle h, int slot, const uint8_t *ext, int ext_stride, 
                      const uint8_t *bc_off, const uint8_t *bc_len, int64_t n, int max_ed);
 int bz_assign_wait(bz_handle h, int slot, int32_t *hit, int8_t *ed, int8_t *end_idx, uint8_t *flags);
 
+/* Pinned (page-locked) host memory for callers that want the boundary at PCIe speed: bz_assign_submit copies pageable
+ * arrays into the engine's pinned staging first (one extra pass over every byte on the host); rows and results that
+ * already live in pinned memory -- bz_host_alloc, or the caller's own hipHostRegister -- are DMA'd straight from / into
+ * the caller's arrays by bz_assign_submit_pinned.  It checks that all eight arrays are pinned (BZ_E_ARG otherwise); the
+ * result arrays are given at submit time and are complete when bz_assign_wait(h, slot, NULL, NULL, NULL, NULL) returns.
+ * Replaces the pickling of every batch to a pool worker and back (helper.py:159-205, read_assignment.py:309-327). */
+int bz_host_alloc(void **out, int64_t bytes);
+int bz_host_free(void *p);
+int bz_assign_submit_pinned(bz_handle h, int slot, const uint8_t *ext, int ext_stride, const uint8_t *ext_len,
+                            const uint8_t *bc_off, const uint8_t *bc_len, int64_t n, int max_ed, int32_t *hit, int8_t *ed,
+                            int8_t *end_idx, uint8_t *flags);
+
 /* The same three steps separately (bench.py keeps rows resident in HBM and times `run`). */
 int bz_assign_stage(bz_handle h, int slot, const uint8_t *ext, int ext_stride, const uint8_t *ext_len,
                     const uint8_t *bc_off, const uint8_t *bc_len, int64_t n);
@@ -221,6 +233,9 @@ int bz_comm_unique_id(uint8_t id[128]);
 int bz_comm_init(bz_handle h, const uint8_t id[128], int n_ranks, int rank);
 int bz_comm_allreduce_counts(bz_handle h);
 int bz_comm_allreduce_f64(bz_handle h, double *inout, int n, int op); /* op 0 sum, 1 max; doubles as barrier */
+/* Exact sum over ranks of a host vector of n int64 (any n; staged through a grow-only device buffer): the per-rank read
+ * counts and part sizes of the file-sharded runs (blaze_amd/dist.py), which must not round-trip through doubles. */
+int bz_comm_allreduce_i64(bz_handle h, int64_t *inout, int64_t n);
 int bz_comm_destroy(bz_handle h);
 
 /* ---- measurement helper ------------------------------------------------------------------ */

@@ -155,5 +155,65 @@ def test_file_rendezvous_roundtrip(tmp_path, monkeypatch):
     monkeypatch.setenv("BLAZE_AMD_RDZV_DIR", str(tmp_path))
     monkeypatch.setenv("MASTER_PORT", "12345")
     uid = bytes(range(128))
-    assert dist.exchange_unique_id(0, lambda: uid) == uid
-    assert dist.exchange_unique_id(1, None, timeout_s=5) == uid
+    assert dist.exchange_unique_id_file(0, lambda: uid) == uid
+    assert dist.exchange_unique_id_file(1, None, timeout_s=5) == uid
+    assert str(os.getppid()) not in os.path.basename(dist._rendezvous_path())      # ranks need not share a parent
+
+
+def test_hub_allgather_three_ranks():
+    """The socket hub that carries the RCCL id (and the scalars when RCCL is unavailable): rank order, bytes and JSON."""
+    import threading
+    from blaze_amd import dist
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    got = {}
+
+    def rank_main(r):
+        hub = dist.Hub(r, 3, addr="127.0.0.1", port=port, timeout_s=30)
+        a = hub.allgather_bytes(bytes([r]) * (r + 1))
+        b = hub.allgather({"rank": r, "t": 1.5 * r})
+        c = hub.allgather_bytes(bytes(range(128)) if r == 0 else b"")[0]        # the id exchange
+        got[r] = (a, b, c)
+        hub.close()
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in (2, 0, 1)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    for r in range(3):
+        a, b, c = got[r]
+        assert a == [b"\x00", b"\x01\x01", b"\x02\x02\x02"]
+        assert b == [{"rank": k, "t": 1.5 * k} for k in range(3)]
+        assert c == bytes(range(128))
+
+
+def _run_bench(args, env_extra, timeout=300):
+    env = dict(os.environ, BLAZE_AMD_BENCH_ENGINE="tests.stub_engine:StubEngine", PYTHONPATH=ROOT, **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        if k not in env_extra:
+            env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+def test_bench_gpus_2_spawns_two_ranks():
+    """`python bench.py --gpus 2` with no launcher: two rank processes, one JSON line, whole-job value, comm named.
+    (Stand-in engine: this checks the launch / rendezvous / reduction logic, which needs no GPU.)"""
+    import json
+    p = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--rows", "4096", "--cells", "64"], {})
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_gpus_requested"] == 2 and out["steps"] == 3
+    assert out["rows_counted"] == 2 * 3 * 4096                  # both ranks' steps were counted: the sum went over the ranks
+    assert "socket-hub" in out["config"]["comm"] and out["config"]["launcher"] == "bench.py --gpus"
+    assert abs(out["value"] - 2 * 4096 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    assert "STAND-IN" in out["data"]
+
+
+def test_bench_refuses_world_size_mismatch():
+    p = _run_bench(["--gpus", "8", "--steps", "1", "--warmup", "0", "--rows", "1024", "--cells", "16"],
+                   dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511"))
+    assert p.returncode == 2 and "WORLD_SIZE=1" in p.stderr and not p.stdout.strip()

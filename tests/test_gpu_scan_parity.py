@@ -410,3 +410,31 @@ def test_rccl_single_rank_collective(engine, tmp_path, monkeypatch):
         comm.barrier()
     finally:
         engine.comm_destroy()
+
+
+def test_submit_pinned_equals_submit(engine):
+    """Rows and results in pinned host memory (bz_host_alloc), DMA'd straight from / into the caller's arrays, on both
+    slots: the same results as the staged submit; pageable arrays are refused, bad rows are named."""
+    rows, wl = _synthetic(50_000, 2000, err=3.0, seed=61)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    engine.set_whitelist_codes16(wl)
+    ref = engine.assign(ext, el, bo, bl, 2)
+    bufs = [engine.pinned_rows(ext, el, bo, bl), engine.pinned_rows(ext[::-1], el[::-1], bo[::-1], bl[::-1])]
+    try:
+        engine.submit_pinned(0, bufs[0], 2)
+        engine.submit_pinned(1, bufs[1], 2)
+        for slot, sl in ((0, slice(None)), (1, slice(None, None, -1))):
+            got = engine.wait_pinned(slot, bufs[slot])
+            for g, r in zip(got, ref):
+                assert np.array_equal(g, r[sl])
+        L = _lib.load()
+        hit = np.empty(ext.shape[0], np.int32)
+        rc = L.bz_assign_submit_pinned(engine._h, 0, ext.ctypes.data, 32, el.ctypes.data, bo.ctypes.data, bl.ctypes.data, ext.shape[0], 2,
+                                       hit.ctypes.data, hit.ctypes.data, hit.ctypes.data, hit.ctypes.data)
+        assert rc == -1 and b"pinned" in L.bz_last_error()
+        bufs[0].ext_len[777] = 99
+        with pytest.raises(_lib.BlazeHipError, match="row 777"):
+            engine.submit_pinned(0, bufs[0], 2)
+    finally:
+        for b in bufs:
+            b.free()

@@ -27,7 +27,7 @@ def short(name):
 
 
 print(f"# rocprofv3 summary ({out})\n")
-print("Command of every pass: `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-two-slots` (1M rows x 5,000 cells).\n")
+print("Command of every pass: `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-two-slots --no-files` (1M rows x 5,000 cells).\n")
 print("## kernel stats (--kernel-trace --stats)\n")
 print("| kernel | calls | total ms | avg us | min us | max us | % |")
 print("|---|---|---|---|---|---|---|")
@@ -59,6 +59,13 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
                        grid=r.get("Grid_Size"), workgroup=r.get("Workgroup_Size"))
 
 result = {"source": out, "kernels": {}}
+try:                                                 # the workload the passes ran (bench.py's own line of the trace pass)
+    with open(os.path.join(out, "trace.json")) as f:
+        line = [ln for ln in f if ln.startswith("{")][-1]
+    cfg = json.loads(line)["config"]
+    result["workload"] = {"rows": cfg["rows_per_gpu"], "cells": cfg["cells"], "max_ed": int(cfg["workload"].split("max_ed ")[1].split(",")[0])}
+except Exception as e:                               # noqa: BLE001
+    print(f"(no workload recorded: {e})\n")
 print("\n## counters per kernel (mean per dispatch; scan kernels split into product / all_rows dispatches)\n")
 for k in sorted(pmc):
     per_sub = defaultdict(list)                      # sub -> [counters dict] in dispatch order

@@ -295,8 +295,9 @@ def assign_read_sharded(comm, fastq_fns, fastq_out, putative_bc_csv, whitelsit_c
     """assign_read (read_assignment.py:253-330) with the FASTQ files sharded over the ranks of `comm`, one process
     per GPU: rank r takes a contiguous run of files (balanced by bytes), counts the reads of its own files, learns
     from the other ranks' counts how many rows of putative_bc.csv precede its files, demultiplexes its files into
-    `part_path(fastq_out, r)`, and after a barrier rank 0 concatenates the parts in rank order into `fastq_out`
-    (gzip members concatenate; plain text concatenates: the bytes are those of a single-process run).  The scan
+    `part_path(fastq_out, r)`, and after ONE all-reduce of the part sizes every rank places its own bytes at its own
+    offset of `fastq_out`, all ranks at once (place_parts; gzip members concatenate; plain text concatenates: the
+    bytes are those of a single-process run).  The scan
     uses no collective; the two totals are summed once.  Returns the GLOBAL (reads assigned, reads seen)."""
     from . import read_assignment as ra
     fastq_fns = [str(f) for f in fastq_fns]
@@ -321,21 +322,7 @@ def assign_read_sharded(comm, fastq_fns, fastq_out, putative_bc_csv, whitelsit_c
             return ra._assign_files_native([eng], fns, putative_bc_csv, out, str(out).endswith('.gz'), restrand, max_ed, batchsize,
                                            ra.DEVICE_BATCH_ROWS, threads, csv_skip_rows=csv_skip_rows)
     demul, total = run_rank(fastq_fns[lo:hi], part, skip) if hi > lo else (0, 0)
-    if hi <= lo:
-        open(part, 'wb').close()
-    sums = comm.allreduce_sum_i64(np.array([demul, total], dtype=np.int64))      # doubles as the barrier before the merge
-    if comm.rank == 0:
-        with open(fastq_out, 'wb') as out:
-            for r in range(comm.world):
-                p = part_path(fastq_out, r)
-                with open(p, 'rb') as f:
-                    while True:
-                        buf = f.read(1 << 24)
-                        if not buf:
-                            break
-                        out.write(buf)
-                os.remove(p)
-    comm.barrier()
+    sums = place_parts(comm, fastq_out, part, extra_sums=(demul, total))
     return int(sums[0]), int(sums[1])
 
 
@@ -348,32 +335,78 @@ def make_comm(engine=None):
 
 
 # ---------------------------------------------------------------------------------------------- stage 1 over files
-def _merge_parts(out_path, parts, skip_header_after_first=False):
-    """Concatenate the ranks' parts in rank order into out_path and delete them.  With skip_header_after_first the
-    first line of every non-empty part but the first is dropped (csv parts each start with the header)."""
-    wrote = False
-    with open(out_path, 'wb') as out:
-        for p in parts:
-            if not os.path.exists(p):
+def _copy_range(src_fd, dst_fd, count, src_off, dst_off):
+    """count bytes from src_fd@src_off to dst_fd@dst_off inside the kernel (copy_file_range: no pass through user
+    space, reflink where the file system has it); pread / pwrite where the call is not available."""
+    use_cfr = hasattr(os, "copy_file_range")
+    while count > 0:
+        if use_cfr:
+            try:
+                n = os.copy_file_range(src_fd, dst_fd, min(count, 1 << 30), src_off, dst_off)
+            except OSError:
+                use_cfr = False
                 continue
-            with open(p, 'rb') as f:
-                if skip_header_after_first and wrote:
-                    f.readline()
-                while True:
-                    buf = f.read(1 << 24)
-                    if not buf:
-                        break
-                    out.write(buf)
-                    wrote = True
-            os.remove(p)
-    if not wrote:
-        os.remove(out_path)                     # no reads at all: the reference never creates the table (main.py:361)
+        else:
+            buf = os.pread(src_fd, min(count, 1 << 24), src_off)
+            n = len(buf)
+            done = 0
+            while done < n:
+                done += os.pwrite(dst_fd, buf[done:], dst_off + done)
+        if n <= 0:
+            raise OSError("short copy while placing a rank's part")
+        count -= n
+        src_off += n
+        dst_off += n
+
+
+def place_parts(comm, out_path, my_part, extra_sums=(), drop_header=False, create_empty=True):
+    """Every rank wrote `my_part` (or nothing).  Put the parts, in rank order, into `out_path` WITHOUT a second serial
+    pass on rank 0: one all-reduce tells every rank all part sizes (it also sums `extra_sums` and is the barrier behind
+    the writes), the first non-empty part is renamed into place (it starts at offset 0), and every other rank copies its
+    own bytes to its own offset, all ranks at once (copy_file_range).  drop_header: every part starts with the same
+    header line and only the first non-empty part keeps it (the stage-1 table).  Returns the summed `extra_sums`."""
+    world, rank = comm.world, comm.rank
+    size = os.path.getsize(my_part) if os.path.exists(my_part) else 0
+    head = 0
+    if drop_header and size:
+        with open(my_part, 'rb') as f:
+            head = len(f.readline())
+    vec = np.zeros(2 * world + len(extra_sums), dtype=np.int64)
+    vec[rank], vec[world + rank] = size, head
+    vec[2 * world:] = extra_sums
+    vec = comm.allreduce_sum_i64(vec)
+    sizes, heads = vec[:world], vec[world:2 * world]
+    nonempty = np.flatnonzero(sizes > 0)
+    first = int(nonempty[0]) if nonempty.size else -1
+    eff = np.array([sizes[r] - (heads[r] if drop_header and r != first else 0) for r in range(world)], dtype=np.int64)
+    if first < 0:
+        if rank == 0 and create_empty:
+            open(out_path, 'wb').close()
+        if os.path.exists(my_part):
+            os.remove(my_part)
+        comm.barrier()
+        return vec[2 * world:]
+    if rank == first:
+        os.replace(my_part, out_path)
+    comm.barrier()                                   # the file exists under its final name from here on
+    if rank != first:
+        if eff[rank] > 0:
+            src, dst = os.open(my_part, os.O_RDONLY), os.open(out_path, os.O_WRONLY)
+            try:
+                _copy_range(src, dst, int(eff[rank]), int(sizes[rank] - eff[rank]), int(eff[:rank].sum()))
+            finally:
+                os.close(src)
+                os.close(dst)
+        if os.path.exists(my_part):
+            os.remove(my_part)
+    comm.barrier()
+    return vec[2 * world:]
 
 
 def putative_bc_files_sharded(comm, fastq_fns, out_csv, kit, umi_len, min_q, batch_size, n_threads, device=None, run_rank=None):
     """The stage-1 loop (main.py:344-364) with the FASTQ files sharded over the ranks of `comm`, one process per GPU:
     rank r searches its contiguous run of files into `part_path(out_csv, r)`, the pass-code counts are summed once, and
-    rank 0 concatenates the parts in rank order (one header) into `out_csv`: the bytes of a single-process run, because
+    every rank places its own part (one header kept) at its offset of `out_csv` (place_parts): the bytes of a single-process run, because
     reference batches never span files (main.py:311-323).  Returns the GLOBAL {pass code: reads}."""
     from . import putative_bc, read_assignment as ra
     fastq_fns = [str(f) for f in fastq_fns]
@@ -386,8 +419,6 @@ def putative_bc_files_sharded(comm, fastq_fns, out_csv, kit, umi_len, min_q, bat
                                                  n_threads=n_threads)
     counts = run_rank(fastq_fns[lo:hi], part) if hi > lo else {}
     codes = (0, 1, 2, 10, 100)
-    sums = comm.allreduce_sum_i64(np.array([counts.get(c, 0) for c in codes], dtype=np.int64))   # doubles as the barrier
-    if comm.rank == 0:
-        _merge_parts(out_csv, [part_path(out_csv, r) for r in range(comm.world)], skip_header_after_first=True)
-    comm.barrier()
+    # no reads at all: the reference never creates the table (main.py:361)
+    sums = place_parts(comm, out_csv, part, extra_sums=[counts.get(c, 0) for c in codes], drop_header=True, create_empty=False)
     return {c: int(v) for c, v in zip(codes, sums) if v}

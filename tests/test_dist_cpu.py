@@ -217,3 +217,67 @@ def test_bench_refuses_world_size_mismatch():
     p = _run_bench(["--gpus", "8", "--steps", "1", "--warmup", "0", "--rows", "1024", "--cells", "16"],
                    dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511"))
     assert p.returncode == 2 and "WORLD_SIZE=1" in p.stderr and not p.stdout.strip()
+
+
+class _ThreadComm:
+    """world ranks as threads of this process: enough to drive dist.place_parts without a launcher."""
+
+    def __init__(self, rank, world, shared):
+        self.rank, self.world, self._s = rank, world, shared
+
+    def barrier(self):
+        self._s["bar"].wait()
+
+    def allreduce_sum_i64(self, arr):
+        import numpy as np
+        a = np.asarray(arr, dtype=np.int64)
+        with self._s["lock"]:
+            self._s["acc"] = self._s.get("acc", 0) + a
+        self._s["bar"].wait()
+        out = self._s["acc"].copy()
+        self._s["bar"].wait()
+        if self.rank == 0:
+            self._s.pop("acc")
+        self._s["bar"].wait()
+        return out
+
+
+def _place(tmp_path, parts, **kw):
+    import threading
+    from blaze_amd import dist
+    world = len(parts)
+    shared = {"bar": threading.Barrier(world), "lock": threading.Lock()}
+    out = str(tmp_path / "final.out")
+    res = {}
+
+    def rank_main(r):
+        part = dist.part_path(out, r)
+        if parts[r] is not None:
+            with open(part, "wb") as f:
+                f.write(parts[r])
+        res[r] = dist.place_parts(_ThreadComm(r, world, shared), out, part, extra_sums=(r, 10), **kw)
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    assert all(list(res[r]) == [sum(range(world)), 10 * world] for r in range(world))
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f]
+    return out
+
+
+def test_place_parts_offsets_headers_and_empty_ranks(tmp_path):
+    big = bytes(range(256)) * 5000                               # 1.28 MB: more than one copy call's worth of nothing special
+    out = _place(tmp_path, [b"aaa\n", big, b"", None, b"zz"])
+    assert open(out, "rb").read() == b"aaa\n" + big + b"zz"
+    # stage-1 table: every part starts with the header, the first NON-EMPTY part keeps it (rank 0 has no reads here)
+    h = b"read_id,putative_bc\n"
+    out = _place(tmp_path, [None, h + b"r1,\nr2,\n", None, h + b"r3,\n", h], drop_header=True, create_empty=False)
+    assert open(out, "rb").read() == h + b"r1,\nr2,\nr3,\n"
+    os.remove(out)
+    # nothing anywhere: step 3 leaves an empty file (the reference opens its output first), stage 1 leaves none
+    out = _place(tmp_path, [None, b"", None])
+    assert os.path.getsize(out) == 0
+    os.remove(out)
+    out = _place(tmp_path, [None, None], drop_header=True, create_empty=False)
+    assert not os.path.exists(out)

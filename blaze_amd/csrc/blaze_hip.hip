@@ -131,7 +131,12 @@ struct bz_engine {
     int tie_rule = 0, shortcut = 1, force_generic = 0, scan_mode = 0, pair_fused = 0, profile = 0;
     // whitelist
     int64_t n_wl = -1;
-    int wl_regular = 0;
+    int wl_regular = 0;                 // the packed fast path is usable (every entry 16-nt ACGT, or all but a few: `mixed`)
+    int64_t n_fast = 0;                 // entries the fast-path structures below are built over (the regular ones, in caller order)
+    int mixed = 0, n_irr = 0;           // a few irregular entries beside the regular ones (k_mixed_fix)
+    int32_t *d_reg_to_orig = nullptr;   //   sub-list index -> index in the caller's list
+    uint8_t *d_irr_bytes = nullptr;     //   the irregular entries, back to back
+    int64_t *d_irr_off = nullptr;
     int n_pairs = 0;
     uint2 *d_planes = nullptr;
     uint4 *d_grams = nullptr;          // 3-gram sets, two barcodes per uint4, padded to 32 barcodes
@@ -205,6 +210,9 @@ void free_whitelist(bz_handle h) {
     hipFree(h->d_pair_bitmap); hipFree(h->d_pair_tab); hipFree(h->d_pair_members); hipFree(h->d_pair_tab8);
     h->d_pair_bitmap = nullptr; h->d_pair_tab = nullptr; h->d_pair_members = nullptr; h->d_pair_tab8 = nullptr;
     h->pair_cap = 0;
+    hipFree(h->d_reg_to_orig); hipFree(h->d_irr_bytes); hipFree(h->d_irr_off);
+    h->d_reg_to_orig = nullptr; h->d_irr_bytes = nullptr; h->d_irr_off = nullptr;
+    h->mixed = 0; h->n_irr = 0; h->n_fast = 0;
     h->d_planes = nullptr; h->d_sorted_codes = nullptr; h->d_sorted_idx = nullptr;
     h->d_wl_bytes = nullptr; h->d_wl_off = nullptr; h->d_counts = nullptr;
     h->n_wl = -1;
@@ -316,7 +324,7 @@ template <int K>
 void launch_scan(bz_handle h, Slot &s) {
     const int block = 256;
     const int grid = (int)((s.n + block - 1) / block);
-    hipLaunchKernelGGL(bz::k_scan_bitparallel<K>, dim3(grid), dim3(block), 0, s.stream, (const uint4 *)h->d_planes, h->n_pairs, (int)h->n_wl,
+    hipLaunchKernelGGL(bz::k_scan_bitparallel<K>, dim3(grid), dim3(block), 0, s.stream, (const uint4 *)h->d_planes, h->n_pairs, (int)h->n_fast,
                        s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
 }
 
@@ -325,7 +333,7 @@ void launch_scan_filtered(bz_handle h, Slot &s) {
     const int block = 256;
     const int grid = (int)((s.n + block - 1) / block);
     hipLaunchKernelGGL(bz::k_scan_filtered<K>, dim3(grid), dim3(block), 0, s.stream, (const uint4 *)h->d_grams, h->d_planes32, h->n_blk,
-                       (int)h->n_wl, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+                       (int)h->n_fast, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
 }
 
 // seeded scan over fast_list; rows it could not fold (more than kMaxEvents near matches) go to
@@ -336,10 +344,10 @@ void launch_scan_seeded(bz_handle h, Slot &s) {
     const int grid = (int)((s.n + block - 1) / block);
     const int plan = K == 2 ? 0 : 1;
     hipLaunchKernelGGL(bz::k_scan_seeded<K>, dim3(grid), dim3(block), 0, s.stream, h->d_seed_tab[plan], h->d_seed_members[plan],
-                       h->d_planes32, (int)h->n_wl, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_redo,
+                       h->d_planes32, (int)h->n_fast, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_redo,
                        s.d_counters + 2, s.d_hit, s.d_ed, s.d_end, s.d_flags);
     hipLaunchKernelGGL(bz::k_scan_filtered<K>, dim3(grid), dim3(block), 0, s.stream, (const uint4 *)h->d_grams, h->d_planes32, h->n_blk,
-                       (int)h->n_wl, s.d_ext, s.stride, s.d_len, s.d_redo, s.d_counters + 2, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+                       (int)h->n_fast, s.d_ext, s.stride, s.d_len, s.d_redo, s.d_counters + 2, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
 }
 
 // pair-seeded scan, two-kernel form (whitelists whose candidate lists fit `pair_cap` slots per row)
@@ -364,7 +372,7 @@ int launch_pair_two_kernels(bz_handle h, Slot &s) {
         h->cand_lds_set = lst_bytes;
     }
     hipLaunchKernelGGL(bz::k_pair_candidates, dim3(ga), dim3(bz::kCandWThreads), lst_bytes, s.stream, h->d_pair_bitmap, h->d_pair_tab8,
-                       h->d_pair_members, (int)h->n_wl, (const uint2 *)s.d_fast_tc, s.d_counters, s.d_cand, h->pair_cap,
+                       h->d_pair_members, (int)h->n_fast, (const uint2 *)s.d_fast_tc, s.d_counters, s.d_cand, h->pair_cap,
                        s.d_cand_cnt);
     if (h->profile) HIP_TRY(hipEventRecord(s.ev[5], s.stream));
     const int block = 256;
@@ -387,10 +395,10 @@ void launch_pair_stream(bz_handle h, Slot &s) {
     const int block = 256;
     const int grid = (int)((s.n + block - 1) / block);
     hipLaunchKernelGGL(bz::k_pair_stream<2>, dim3(grid), dim3(block), 0, s.stream, h->d_pair_tab, h->d_pair_members, h->d_planes32,
-                       (int)h->n_wl, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_redo, s.d_counters + 2,
+                       (int)h->n_fast, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_redo, s.d_counters + 2,
                        s.d_hit, s.d_ed, s.d_end, s.d_flags);
     hipLaunchKernelGGL(bz::k_scan_filtered<2>, dim3(grid), dim3(block), 0, s.stream, (const uint4 *)h->d_grams, h->d_planes32, h->n_blk,
-                       (int)h->n_wl, s.d_ext, s.stride, s.d_len, s.d_redo, s.d_counters + 2, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+                       (int)h->n_fast, s.d_ext, s.stride, s.d_len, s.d_redo, s.d_counters + 2, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
 }
 
 // the striped totals behind counts[n_wl+2] -> counts[n_wl], counts[n_wl+1]
@@ -414,11 +422,11 @@ int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed
         const dim3 cgrid((n + bz::kClassifyThreads * bz::kClassifyRows - 1) / (bz::kClassifyThreads * bz::kClassifyRows));
         if (packed)
             hipLaunchKernelGGL(bz::k_classify_packed, cgrid, dim3(bz::kClassifyThreads), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
-                               s.d_bcl, n, h->wl_regular, h->d_sorted_pairs, (int)h->n_wl, h->d_bucket, h->d_bucket8, h->bucket_bits, h->shortcut,
+                               s.d_bcl, n, h->wl_regular, h->d_sorted_pairs, (int)h->n_fast, h->d_bucket, h->d_bucket8, h->bucket_bits, h->shortcut,
                                h->force_generic, max_ed, s.d_fast, (uint2 *)s.d_fast_tc, s.d_gen, s.d_counters, s.d_hit, s.d_ed, s.d_end, s.d_flags);
         else
             hipLaunchKernelGGL(bz::k_classify, cgrid, dim3(bz::kClassifyThreads), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
-                               s.d_bcl, n, h->wl_regular, h->d_sorted_codes, h->d_sorted_idx, (int)h->n_wl, h->d_bucket, h->bucket_bits, h->shortcut,
+                               s.d_bcl, n, h->wl_regular, h->d_sorted_codes, h->d_sorted_idx, (int)h->n_fast, h->d_bucket, h->bucket_bits, h->shortcut,
                                h->force_generic, max_ed, s.d_fast, s.d_gen, s.d_counters, s.d_hit, s.d_ed, s.d_end, s.d_flags);
         HIP_TRY(hipGetLastError());
     }
@@ -428,7 +436,7 @@ int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed
         // filter + verify over the whole whitelist; mode 1 = brute force (also what max_ed 3 takes: its
         // seeds and 3-gram sets are too weak to pay)
         // (event words hold the barcode index in 25 bits: larger whitelists take the filtered scan)
-        const bool seeded = (h->scan_mode == 0 || h->scan_mode == 3) && max_ed <= 2 && h->n_wl < ((int64_t)1 << 25);
+        const bool seeded = (h->scan_mode == 0 || h->scan_mode == 3) && max_ed <= 2 && h->n_fast < ((int64_t)1 << 25);
         const bool filtered = !seeded && h->scan_mode != 1 && max_ed <= 2;
         switch (max_ed) {
             case 0: if (seeded) launch_scan_seeded<0>(h, s); else if (filtered) launch_scan_filtered<0>(h, s); else launch_scan<0>(h, s); break;
@@ -440,6 +448,17 @@ int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed
                     else if (filtered) launch_scan_filtered<2>(h, s); else launch_scan<2>(h, s); break;
             default: launch_scan<3>(h, s); break;
         }
+        HIP_TRY(hipGetLastError());
+    }
+    if (h->mixed) {
+        // indices of the regular sub-list -> caller's indices; scored rows within max_ed of an irregular entry -> fix list
+        // (the hand-over list's buffer: its rows have been consumed by now; counter 3)
+        hipLaunchKernelGGL(bz::k_mixed_fix, dim3(std::min((n + 255) / 256, 8 * h->n_cu)), dim3(256), 0, s.stream, h->d_reg_to_orig, h->d_irr_bytes,
+                           h->d_irr_off, h->n_irr, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, n, max_ed, h->tie_rule, s.d_redo,
+                           s.d_counters + 3, s.d_hit, s.d_flags);
+        hipLaunchKernelGGL(bz::k_scan_generic, dim3(std::min((n + 63) / 64, 16 * h->n_cu)), dim3(64), 0, s.stream, h->d_wl_bytes, h->d_wl_off, (int)h->n_wl,
+                           s.d_ext, s.stride, s.d_len, s.d_off, s.d_bcl, s.d_redo, s.d_counters + 3, max_ed, h->tie_rule,
+                           h->shortcut, s.d_hit, s.d_ed, s.d_end, s.d_flags);
         HIP_TRY(hipGetLastError());
     }
     if (prof) HIP_TRY(hipEventRecord(s.ev[2], s.stream));
@@ -565,13 +584,20 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
     free_whitelist(h);
 
     const int64_t total = n ? offsets[n] - offsets[0] : 0;
-    bool regular = n > 0;
-    for (int64_t k = 0; k < n && regular; ++k) {
-        if (offsets[k + 1] - offsets[k] != bz::kBcLen) { regular = false; break; }
+    // entries of the packed shape (16-nt ACGT) in caller order; a FEW others beside them keep the fast path (k_mixed_fix),
+    // more than kMaxIrregular send every row through the byte-wise scan
+    constexpr int64_t kMaxIrregular = 256;
+    std::vector<int32_t> reg_pos, irr_pos;
+    for (int64_t k = 0; k < n; ++k) {
+        bool ok = offsets[k + 1] - offsets[k] == bz::kBcLen;
         const char *w = bytes + offsets[k];
-        for (int i = 0; i < bz::kBcLen; ++i)
-            if (w[i] != 'A' && w[i] != 'C' && w[i] != 'G' && w[i] != 'T') { regular = false; break; }
+        for (int i = 0; ok && i < bz::kBcLen; ++i) ok = w[i] == 'A' || w[i] == 'C' || w[i] == 'G' || w[i] == 'T';
+        if (ok) reg_pos.push_back((int32_t)k);
+        else if ((int64_t)irr_pos.size() <= kMaxIrregular) irr_pos.push_back((int32_t)k);
     }
+    const int64_t nf = (int64_t)reg_pos.size();
+    const bool regular = nf > 0 && n - nf <= kMaxIrregular;
+    const bool mixed = regular && nf < n;
     // byte form (generic kernel + histogram size)
     std::vector<int64_t> off(n + 1);
     for (int64_t k = 0; k <= n; ++k) off[k] = offsets[k] - offsets[0];
@@ -589,12 +615,12 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
     h->n_pairs = 0;
     if (regular) {
         // 2-bit planes, two barcodes per 32-bit word, padded to a multiple of 2 pairs with copies of
-        // barcode 0 (indices >= n are ignored by the kernel).
-        const int64_t n_pairs = ((n + 3) / 4) * 2;
+        // barcode 0 (indices >= nf are ignored by the kernel).
+        const int64_t n_pairs = ((nf + 3) / 4) * 2;
         std::vector<uint2> planes(n_pairs);
-        std::vector<uint32_t> codes(n);
+        std::vector<uint32_t> codes(nf);
         auto plane16 = [&](int64_t k, uint32_t &hi, uint32_t &lo, uint32_t &code) {
-            const char *w = bytes + offsets[k < n ? k : 0];
+            const char *w = bytes + offsets[reg_pos[k < nf ? k : 0]];
             hi = lo = code = 0;
             for (int i = 0; i < bz::kBcLen; ++i) {
                 uint32_t c = ((uint32_t)(unsigned char)w[i] >> 1) & 3u;
@@ -605,38 +631,38 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
             uint32_t h0, l0, c0, h1, l1, c1;
             plane16(2 * p, h0, l0, c0); plane16(2 * p + 1, h1, l1, c1);
             planes[p] = make_uint2(h0 | (h1 << 16), l0 | (l1 << 16));
-            if (2 * p < n) codes[2 * p] = c0;
-            if (2 * p + 1 < n) codes[2 * p + 1] = c1;
+            if (2 * p < nf) codes[2 * p] = c0;
+            if (2 * p + 1 < nf) codes[2 * p + 1] = c1;
         }
-        std::vector<int32_t> idx(n);
+        std::vector<int32_t> idx(nf);
         std::iota(idx.begin(), idx.end(), 0);
         std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return codes[a] < codes[b]; });
-        std::vector<uint32_t> sorted(n);
-        for (int64_t k = 0; k < n; ++k) sorted[k] = codes[idx[k]];
+        std::vector<uint32_t> sorted(nf);
+        for (int64_t k = 0; k < nf; ++k) sorted[k] = codes[idx[k]];
         HIP_TRY(hipMalloc(&h->d_planes, n_pairs * sizeof(uint2)));
-        HIP_TRY(hipMalloc(&h->d_sorted_codes, n * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&h->d_sorted_idx, n * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&h->d_sorted_codes, nf * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&h->d_sorted_idx, nf * sizeof(int32_t)));
         HIP_TRY(hipMemcpy(h->d_planes, planes.data(), n_pairs * sizeof(uint2), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(h->d_sorted_codes, sorted.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(h->d_sorted_idx, idx.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->d_sorted_codes, sorted.data(), nf * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->d_sorted_idx, idx.data(), nf * sizeof(int32_t), hipMemcpyHostToDevice));
         {
-            std::vector<uint2> pairs(n);
-            for (int64_t k = 0; k < n; ++k) pairs[k] = make_uint2(sorted[k], (uint32_t)idx[k]);
-            HIP_TRY(hipMalloc(&h->d_sorted_pairs, n * sizeof(uint2)));
-            HIP_TRY(hipMemcpy(h->d_sorted_pairs, pairs.data(), n * sizeof(uint2), hipMemcpyHostToDevice));
+            std::vector<uint2> pairs(nf);
+            for (int64_t k = 0; k < nf; ++k) pairs[k] = make_uint2(sorted[k], (uint32_t)idx[k]);
+            HIP_TRY(hipMalloc(&h->d_sorted_pairs, nf * sizeof(uint2)));
+            HIP_TRY(hipMemcpy(h->d_sorted_pairs, pairs.data(), nf * sizeof(uint2), hipMemcpyHostToDevice));
         }
         h->n_pairs = (int)n_pairs;
 
         // bucket table for the shortcut look-up: ~4 buckets per barcode, 2^8 .. 2^24 buckets
         int bits = 8;
-        while (bits < 24 && ((int64_t)1 << bits) < 4 * n) ++bits;
+        while (bits < 24 && ((int64_t)1 << bits) < 4 * nf) ++bits;
         const int64_t nb = (int64_t)1 << bits;
         std::vector<int32_t> bucket(nb + 1);
         {
             int64_t k = 0;
             for (int64_t b = 0; b <= nb; ++b) {
                 const uint64_t lim = (uint64_t)b << (32 - bits);     // first code of bucket b
-                while (k < n && (uint64_t)sorted[k] < lim) ++k;
+                while (k < nf && (uint64_t)sorted[k] < lim) ++k;
                 bucket[b] = (int32_t)k;
             }
         }
@@ -654,10 +680,10 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
         }
 
         // filtered scan: 64-bit 3-gram set per barcode (padding = all ones: never passes), planes32
-        const int64_t n_blk = (n + bz::kFilterBlock - 1) / bz::kFilterBlock;
+        const int64_t n_blk = (nf + bz::kFilterBlock - 1) / bz::kFilterBlock;
         std::vector<uint2> grams(n_blk * bz::kFilterBlock, make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu));
-        std::vector<uint32_t> planes32(n);
-        for (int64_t k = 0; k < n; ++k) {
+        std::vector<uint32_t> planes32(nf);
+        for (int64_t k = 0; k < nf; ++k) {
             const uint32_t c = codes[k];
             uint64_t set = 0;
             for (int i = 0; i + 3 <= bz::kBcLen; ++i) set |= (uint64_t)1 << ((c >> (2 * i)) & 63u);
@@ -667,9 +693,9 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
             planes32[k] = hi | (lo << 16);
         }
         HIP_TRY(hipMalloc(&h->d_grams, grams.size() * sizeof(uint2)));
-        HIP_TRY(hipMalloc(&h->d_planes32, n * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&h->d_planes32, nf * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(h->d_grams, grams.data(), grams.size() * sizeof(uint2), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(h->d_planes32, planes32.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->d_planes32, planes32.data(), nf * sizeof(uint32_t), hipMemcpyHostToDevice));
         h->n_blk = (int)n_blk;
 
         // seed index (k_scan_seeded): per piece a CSR bucket table over the piece's 2-bit code
@@ -678,18 +704,18 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
         for (int pl = 0; pl < 2; ++pl) {
             size_t tab_size = 0;
             for (int q = 0; q < plan_n[pl]; ++q) tab_size += ((size_t)1 << (2 * plan_len[pl][q])) + 1;
-            std::vector<int32_t> tab(tab_size), mem((size_t)plan_n[pl] * n);
+            std::vector<int32_t> tab(tab_size), mem((size_t)plan_n[pl] * nf);
             size_t base = 0;
             for (int q = 0; q < plan_n[pl]; ++q) {
                 const size_t nb = (size_t)1 << (2 * plan_len[pl][q]);
                 const uint32_t mask = (uint32_t)(nb - 1);
                 int32_t *t = tab.data() + base;
                 std::fill(t, t + nb + 1, 0);
-                for (int64_t k = 0; k < n; ++k) ++t[((codes[k] >> (2 * plan_off[pl][q])) & mask) + 1];
+                for (int64_t k = 0; k < nf; ++k) ++t[((codes[k] >> (2 * plan_off[pl][q])) & mask) + 1];
                 for (size_t b = 0; b < nb; ++b) t[b + 1] += t[b];
                 std::vector<int32_t> fill(t, t + nb);
-                int32_t *m = mem.data() + (size_t)q * n;
-                for (int64_t k = 0; k < n; ++k) m[fill[(codes[k] >> (2 * plan_off[pl][q])) & mask]++] = (int32_t)k;
+                int32_t *m = mem.data() + (size_t)q * nf;
+                for (int64_t k = 0; k < nf; ++k) m[fill[(codes[k] >> (2 * plan_off[pl][q])) & mask]++] = (int32_t)k;
                 base += nb + 1;
             }
             HIP_TRY(hipMalloc(&h->d_seed_tab[pl], tab.size() * sizeof(int32_t)));
@@ -704,20 +730,20 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
             const int pa[bz::kPairCount] = {0, 0, 0, 1, 1, 2}, pb[bz::kPairCount] = {1, 2, 3, 2, 3, 3};
             std::vector<uint32_t> bitmap((size_t)bz::kPairCount * bz::kPairBmWords, 0u);
             std::vector<int32_t> tab((size_t)bz::kPairCount * bz::kPairTab);
-            std::vector<uint2> mem((size_t)bz::kPairCount * n);
+            std::vector<uint2> mem((size_t)bz::kPairCount * nf);
             for (int p = 0; p < bz::kPairCount; ++p) {
                 auto key = [&](int64_t k) { return (((codes[k] >> (8 * pa[p])) & 0xFFu) << 8) | ((codes[k] >> (8 * pb[p])) & 0xFFu); };
                 int32_t *t = tab.data() + (size_t)p * bz::kPairTab;
                 std::fill(t, t + bz::kPairTab, 0);
-                for (int64_t k = 0; k < n; ++k) {
+                for (int64_t k = 0; k < nf; ++k) {
                     const uint32_t ky = key(k);
                     ++t[ky + 1];
                     bitmap[(size_t)p * bz::kPairBmWords + (ky >> 5)] |= 1u << (ky & 31u);
                 }
                 for (int b = 0; b < bz::kPairTab - 1; ++b) t[b + 1] += t[b];
                 std::vector<int32_t> fill(t, t + bz::kPairTab - 1);
-                uint2 *m = mem.data() + (size_t)p * n;
-                for (int64_t k = 0; k < n; ++k) m[fill[key(k)]++] = make_uint2((uint32_t)k, planes32[k]);
+                uint2 *m = mem.data() + (size_t)p * nf;
+                for (int64_t k = 0; k < nf; ++k) m[fill[key(k)]++] = make_uint2((uint32_t)k, planes32[k]);
             }
             HIP_TRY(hipMalloc(&h->d_pair_bitmap, bitmap.size() * sizeof(uint32_t)));
             HIP_TRY(hipMalloc(&h->d_pair_tab, tab.size() * sizeof(int32_t)));
@@ -726,20 +752,20 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
             HIP_TRY(hipMemcpy(h->d_pair_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(h->d_pair_members, mem.data(), mem.size() * sizeof(uint2), hipMemcpyHostToDevice));
             // two-kernel form: 8-byte table entries and a per-row candidate capacity of the expected number of candidates
-            // (131 probes x n / 65536 barcodes per bucket by chance, + 6 for a true barcode met through several pairs)
+            // (131 probes x nf / 65536 barcodes per bucket by chance, + 6 for a true barcode met through several pairs)
             // + 5 sigma + 8: 48 at 5k cells, 64 at 10k, 88 at 20k, 144 at 40k (6.5 sigma or more once rounded).  A row above
             // it (the rows of low-complexity whitelists) is handed to the ordered scan, which costs a whole-whitelist
             // pass: milliseconds at 40k barcodes, so the capacity must not be tight (120 at 40k cells: 58 of 586K rows
             // over it, step 0.82 -> 4.9 ms).  The capacity also sizes k_pair_candidates' lists in LDS: up to 93 rows two
             // workgroups share a CU (the old 2 x chance + 40 = 136 rows at 20k cells allowed one, and configs[2] ran
-            // 17 % slower than with the lists in global memory).  Indices are 16 bits there: n < 48K.
-            const double chance = 131.0 * (double)n / 65536.0 + 6.0;
+            // 17 % slower than with the lists in global memory).  Indices are 16 bits there: nf < 48K.
+            const double chance = 131.0 * (double)nf / 65536.0 + 6.0;
             const int cap = ((int)std::ceil(chance + 5.0 * std::sqrt(chance) + 8.0) + 7) / 8 * 8;
-            if (n < 49152) {
+            if (nf < 49152) {
                 std::vector<uint2> tab8((size_t)bz::kPairCount * 65536);
                 for (int p = 0; p < bz::kPairCount; ++p) {
                     const int32_t *t = tab.data() + (size_t)p * bz::kPairTab;
-                    const uint2 *m = mem.data() + (size_t)p * n;
+                    const uint2 *m = mem.data() + (size_t)p * nf;
                     for (int b = 0; b < 65536; ++b) {
                         const uint32_t c = (uint32_t)(t[b + 1] - t[b]);       // {size (saturating) | offset << 8, first member}
                         tab8[(size_t)p * 65536 + b] = make_uint2(std::min(c, 255u) | ((uint32_t)t[b] << 8), c ? m[t[b]].x : 0u);
@@ -749,6 +775,22 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
                 HIP_TRY(hipMemcpy(h->d_pair_tab8, tab8.data(), tab8.size() * sizeof(uint2), hipMemcpyHostToDevice));
                 h->pair_cap = cap;
             }
+        }
+        h->n_fast = nf;
+        if (mixed) {
+            std::vector<char> ib;
+            std::vector<int64_t> io(1, 0);
+            for (int32_t k : irr_pos) {
+                ib.insert(ib.end(), bytes + offsets[k], bytes + offsets[k + 1]);
+                io.push_back((int64_t)ib.size());
+            }
+            HIP_TRY(hipMalloc(&h->d_reg_to_orig, nf * sizeof(int32_t)));
+            HIP_TRY(hipMalloc(&h->d_irr_bytes, std::max<size_t>(ib.size(), 1)));
+            HIP_TRY(hipMalloc(&h->d_irr_off, io.size() * sizeof(int64_t)));
+            HIP_TRY(hipMemcpy(h->d_reg_to_orig, reg_pos.data(), nf * sizeof(int32_t), hipMemcpyHostToDevice));
+            if (!ib.empty()) HIP_TRY(hipMemcpy(h->d_irr_bytes, ib.data(), ib.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(h->d_irr_off, io.data(), io.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+            h->mixed = 1; h->n_irr = (int)irr_pos.size();
         }
     }
     h->n_wl = n;
@@ -958,7 +1000,7 @@ int bz_slot_timing(bz_handle h, int slot, float ms[8], int64_t counts[8]) {
     if (counts) {
         memset(counts, 0, 8 * sizeof(int64_t));
         counts[0] = s.n; counts[1] = s.h_counters[0]; counts[2] = s.h_counters[1]; counts[3] = h->n_wl;
-        counts[4] = s.h_counters[2];
+        counts[4] = s.h_counters[2]; counts[5] = s.h_counters[3];
     }
     return BZ_OK;
 }

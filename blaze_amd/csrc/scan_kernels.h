@@ -1324,6 +1324,41 @@ __global__ __launch_bounds__(256) void k_pair_tail(
                       ext_len, bc_off, bc_len, gen_list, max_ed, tie, shortcut, hit_out, ed_out, end_out, flags_out);
 }
 
+// Mixed whitelists: a list with a FEW entries outside the packed shape (not 16 nt, or not all ACGT) keeps the fast path.
+// The seed indices, planes and the shortcut table are built over the regular entries only (the sub-list keeps their
+// relative order), so every result of the fast kernels is an index into the sub-list.  This kernel, behind the scan,
+//   (1) maps those indices back to the caller's order (reg_to_orig), and
+//   (2) tests every scored row against the irregular entries (byte-wise DP, the same routine k_scan_generic runs): a row
+//       within max_ed of one of them is listed in fix_list and re-scored by k_scan_generic over the WHOLE list in the
+//       caller's order.  Every other row is final: the reference's fold (read_assignment.py:73-85) ignores an entry
+//       whose distance exceeds best_ed <= max_ed, so leaving the irregular entries out changes nothing for it, and the
+//       relative order of the entries that do take part is kept.  Rows that took the exact-match shortcut are final
+//       too (:61-62 returns before the fold), and a regular putative barcode can only equal a regular entry.
+__global__ __launch_bounds__(256) void k_mixed_fix(
+    const int32_t *__restrict__ reg_to_orig, const uint8_t *__restrict__ irr_bytes, const int64_t *__restrict__ irr_off, int n_irr,
+    const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
+    const int32_t *__restrict__ fast_list, const int32_t *__restrict__ n_fast_ptr, int n, int max_ed, int tie,
+    int32_t *__restrict__ fix_list, int32_t *__restrict__ n_fix, int32_t *__restrict__ hit, const uint8_t *__restrict__ flags) {
+    const int first = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
+    for (int r = first; r < n; r += step) {
+        const int h = hit[r];
+        if (h >= 0 && !(flags[r] & kFlagGeneric)) hit[r] = reg_to_orig[h];
+    }
+    const int n_list = *n_fast_ptr;
+    for (int slot = first; slot < n_list; slot += step) {
+        const int r = fast_list[slot];
+        const uint8_t *row = ext + (size_t)r * ext_stride;
+        const int len = ext_len[r];
+        bool near = false;
+        for (int k = 0; k < n_irr && !near; ++k) {
+            const int64_t o = irr_off[k];
+            int end;
+            near = dev_sub_edit_distance(irr_bytes + o, (int)(irr_off[k + 1] - o), row, len, max_ed, tie, end) <= max_ed;
+        }
+        if (near) fix_list[atomicAdd(n_fix, 1)] = r;
+    }
+}
+
 // far[i] = 1 iff every string of set B is at global edit distance >= min_ed from A[i]: the test of the empty-drop list,
 // `min([edit_distance(k, x, max_ed=5) for x in cells_bc.keys()]) >= 5` (main.py:249-250, :274-275).  lane = A[i]; the B
 // strings are wave-uniform (scalar loads), a lane stops at the first close one.  Lengths <= kGenericMax (host checks).

@@ -189,7 +189,7 @@ class Engine:
         check(self._L.bz_slot_timing(self._h, slot, ms, cnt))
         return dict(total_ms=ms[0], classify_ms=ms[1], scan_ms=ms[2], generic_ms=ms[3], hist_ms=ms[4],
                     candidates_ms=ms[5], verify_ms=ms[6],
-                    rows=cnt[0], rows_bitparallel=cnt[1], rows_generic=cnt[2], n_whitelist=cnt[3], rows_redo=cnt[4])
+                    rows=cnt[0], rows_bitparallel=cnt[1], rows_generic=cnt[2], n_whitelist=cnt[3], rows_redo=cnt[4], rows_mixed_fix=cnt[5])
 
     # -- single pair (the FFI the reference binds) ---------------------------------------
     def sub_edit_distance(self, a, b, max_ed: int):

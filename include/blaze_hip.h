@@ -131,7 +131,8 @@ int bz_slot_sync(bz_handle h, int slot);
  * [2] bit-parallel scan, [3] generic scan, [4] histogram, [5] k_pair_candidates and [6] k_pair_verify inside [2] (zero when
  * another scan ran); counts[0] rows, [1] rows scored by the
  * bit-parallel kernels, [2] rows scored by the generic kernel, [3] whitelist size, [4] rows the seeded
- * scan handed to the filtered scan (more than 8 near matches). */
+ * scan handed to the filtered scan (more than 8 near matches), [5] rows of a MIXED whitelist (regular entries + at most
+ * 256 irregular ones) that came within max_ed of an irregular entry and were re-scored over the whole list. */
 int bz_slot_timing(bz_handle h, int slot, float ms[8], int64_t counts[8]);
 
 /* ---- the entry point that allocates nothing ------------------------------------------------------------------

@@ -160,7 +160,8 @@ def test_bytes_past_the_text_are_ignored(engine, oracle, scan_mode):
 
 
 def test_irregular_whitelist(engine, oracle):
-    """Whitelist with an N barcode, a 15-mer, an 18-mer and an empty string: generic kernel only."""
+    """Whitelist with an N barcode, a 15-mer, an 18-mer and an empty string.  The empty string is within any max_ed of
+    every text, so the mixed path re-scores every scored row over the whole list: slow, and exact."""
     rows, wl = _synthetic(800, 60, err=2.0, seed=14)
     ext, el, bo, bl = synth.pack_ext(rows)
     wl_list = [w.tobytes() for w in wl]
@@ -170,6 +171,48 @@ def test_irregular_whitelist(engine, oracle):
     wl_list.insert(30, b"")
     _compare(engine, oracle, ext, el, bo, bl, wl_list, 2)
     _compare(engine, oracle, ext, el, bo, bl, wl_list, 1, tie=1)
+
+
+@pytest.mark.parametrize("scan_mode", **MODES)
+@pytest.mark.parametrize("max_ed", [2, 1])
+def test_mixed_whitelist_keeps_the_fast_path(engine, oracle, max_ed, scan_mode):
+    """5,000 regular barcodes + a handful of irregular entries (15-mer, 18-mer, N, lower case -- all variants of REAL
+    cell barcodes, so rows do come close to them, and at the front / middle / end of the list, so the order-dependent
+    fold sees them on both sides of the regular near matches): the regular rows stay on the seeded kernels, only rows
+    within max_ed of an irregular entry are re-scored over the whole list, and every row equals the oracle's."""
+    rows, wl = _synthetic(10_000, 5000, err=3.0, seed=71)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    wl_list = [w.tobytes() for w in wl]
+    w0, w1, w2, w3, w4 = (wl_list[k] for k in (5, 1200, 2500, 3700, 4999))
+    wl_list.insert(0, w0[:15])                      # a 15-mer in front of everything
+    wl_list.insert(1500, w1[:7] + b"N" + w1[8:])
+    wl_list[wl_list.index(w2)] = w2 + b"AC"         # an 18-mer INSTEAD of its cell's barcode: that cell's rows can only go to it
+    wl_list.insert(4000, w3.lower())
+    wl_list.append(w4[1:])                          # a 15-mer suffix at the very end
+    wl_list.append(w0[:15])                         # and a duplicate of the first irregular entry
+    hit, ed, end, flags = _compare(engine, oracle, ext, el, bo, bl, wl_list, max_ed, scan_mode=scan_mode)
+    t = engine.timing(0)
+    assert t["rows_generic"] == 0 and t["rows_bitparallel"] > 2000
+    assert 0 < t["rows_mixed_fix"] < 100, t                          # the rows of five cells out of 5,000, no more
+    assert (hit == wl_list.index(w2 + b"AC")).sum() > 0              # some rows ARE assigned to an irregular entry
+    counts = None
+    engine.counts_reset()
+    hit2, *_ = engine.assign(ext, el, bo, bl, max_ed)
+    counts = engine.counts()
+    assert np.array_equal(hit2, hit)
+    assert np.array_equal(counts[:len(wl_list)], np.bincount(hit[hit >= 0], minlength=len(wl_list)))   # caller's indices
+
+
+def test_too_many_irregular_entries_take_the_generic_scan(engine, oracle):
+    rows, wl = _synthetic(600, 400, err=2.0, seed=72)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    wl_list = [w.tobytes() for w in wl]
+    for k in range(0, 400, 1):
+        if k % 4 != 3:
+            wl_list[k] = wl_list[k][:15]            # 300 irregular entries: above the limit of the mixed path
+    _compare(engine, oracle, ext, el, bo, bl, wl_list, 2)
+    t = engine.timing(0)
+    assert t["rows_bitparallel"] == 0 and t["rows_generic"] > 300
 
 
 def test_near_duplicate_whitelist_order_dependence(engine, oracle):

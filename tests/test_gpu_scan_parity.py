@@ -184,6 +184,11 @@ def test_mixed_whitelist_keeps_the_fast_path(engine, oracle, max_ed, scan_mode):
     ext, el, bo, bl = synth.pack_ext(rows)
     wl_list = [w.tobytes() for w in wl]
     w0, w1, w2, w3, w4 = (wl_list[k] for k in (5, 1200, 2500, 3700, 4999))
+    some = np.flatnonzero((bl == 16) & (el == 20))[:40]              # reads of those five cells, whatever the draw gave them
+    for j, r in enumerate(some):
+        ext[r, 2:18] = np.frombuffer((w0, w1, w2, w3, w4)[j % 5], dtype=np.uint8)
+        if j >= 20:
+            ext[r, 9] = ord("ACGT"[(("ACGT".index(chr(ext[r, 9]))) + 1) % 4])        # ... half of them with one substitution
     wl_list.insert(0, w0[:15])                      # a 15-mer in front of everything
     wl_list.insert(1500, w1[:7] + b"N" + w1[8:])
     wl_list[wl_list.index(w2)] = w2 + b"AC"         # an 18-mer INSTEAD of its cell's barcode: that cell's rows can only go to it

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libblaze_hip.so")
 
-BZ_OPT_TIE_RULE, BZ_OPT_SHORTCUT, BZ_OPT_FORCE_GENERIC, BZ_OPT_SCAN_MODE, BZ_OPT_PAIR_FUSED, BZ_OPT_PROFILE = 1, 2, 3, 4, 5, 6
+BZ_OPT_TIE_RULE, BZ_OPT_SHORTCUT, BZ_OPT_FORCE_GENERIC, BZ_OPT_SCAN_MODE, BZ_OPT_PAIR_FUSED, BZ_OPT_PROFILE, BZ_OPT_GZ_LEVEL = 1, 2, 3, 4, 5, 6, 7
 BZ_F_EXACT, BZ_F_BLANK, BZ_F_AMBIG, BZ_F_GENERIC, BZ_F_INVALID = 1, 2, 4, 8, 16
 BZ_NOALLOC_MAX_ROWS = 262144
 BZ_EXT_MAX = 64

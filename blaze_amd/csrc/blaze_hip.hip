@@ -128,7 +128,7 @@ static std::mutex g_scratch_mu;
 
 struct bz_engine {
     int device = 0;
-    int tie_rule = 0, shortcut = 1, force_generic = 0, scan_mode = 0, pair_fused = 0, profile = 0;
+    int tie_rule = 0, shortcut = 1, force_generic = 0, scan_mode = 0, pair_fused = 0, profile = 0, gz_level = 4;
     // whitelist
     int64_t n_wl = -1;
     int wl_regular = 0;                 // the packed fast path is usable (every entry 16-nt ACGT, or all but a few: `mixed`)
@@ -570,6 +570,7 @@ int bz_set_option(bz_handle h, int option, int64_t value) {
         case BZ_OPT_SCAN_MODE: if (value < 0 || value > 3) return fail(BZ_E_ARG, "scan mode must be 0..3"); h->scan_mode = (int)value; return BZ_OK;
         case BZ_OPT_PAIR_FUSED: h->pair_fused = value ? 1 : 0; return BZ_OK;
         case BZ_OPT_PROFILE: h->profile = value ? 1 : 0; return BZ_OK;
+        case BZ_OPT_GZ_LEVEL: if (value < 1 || value > 9) return fail(BZ_E_ARG, "gz level must be 1..9"); h->gz_level = (int)value; return BZ_OK;
     }
     return fail(BZ_E_ARG, "unknown option %d", option);
 }
@@ -1272,7 +1273,12 @@ int bz_assign_files_from(bz_handle *engines, int n_engines, const char *const *f
     job.gz = gz != 0; job.restrand = restrand != 0; job.max_ed = max_ed; job.batch_size = batch_size;
     job.n_threads = n_threads; job.device_batch_rows = std::min<int64_t>(device_batch_rows, (int64_t)1 << 24);
     job.csv_skip_rows = csv_skip_rows;
-    if (const char *lv = getenv("BLAZE_AMD_GZ_LEVEL")) {   // the reference's gzip.compress uses level 9; the decompressed stream is the contract
+    // zlib level of the `.gz` members.  The reference's gzip.compress uses 9; the decompressed stream is the contract (the
+    // compressed bytes carry a wall-clock mtime and are never reproducible).  Default 4: on FASTQ text level 9
+    // is 3.7 % smaller and 14x slower per host thread (profiles/r02e_gz_perf.txt); BZ_OPT_GZ_LEVEL / BLAZE_AMD_GZ_LEVEL=9
+    // give the reference's setting back.
+    job.gz_level = engines[0]->gz_level;
+    if (const char *lv = getenv("BLAZE_AMD_GZ_LEVEL")) {
         const int v = atoi(lv);
         if (v >= 1 && v <= 9) job.gz_level = v;
     }

@@ -301,7 +301,7 @@ struct Job {
     std::vector<std::string> fastq_fns;
     std::string csv, out_path;
     bool gz = false, restrand = true;
-    int max_ed = 2, batch_size = 1000, n_threads = 8, gz_level = 9;
+    int max_ed = 2, batch_size = 1000, n_threads = 8, gz_level = 4;
     int64_t device_batch_rows = 1 << 16;
     int64_t csv_skip_rows = 0;               // rows of the table that belong to reads of earlier FASTQ files (another rank's)
 };

@@ -318,7 +318,7 @@ def assign_read_sharded(comm, fastq_fns, fastq_out, putative_bc_csv, whitelsit_c
             dev = device if device is not None else ra._device_ids(None)[0]
             eng = ra.get_engine(dev)
             ra._ensure_whitelist(eng, ordered)
-            threads = max(1, min(int(n_process or 1), os.cpu_count() or 1, 64))
+            threads = max(1, min(int(n_process or 1), os.cpu_count() or 1, 256))
             return ra._assign_files_native([eng], fns, putative_bc_csv, out, str(out).endswith('.gz'), restrand, max_ed, batchsize,
                                            ra.DEVICE_BATCH_ROWS, threads, csv_skip_rows=csv_skip_rows)
     demul, total = run_rank(fastq_fns[lo:hi], part, skip) if hi > lo else (0, 0)

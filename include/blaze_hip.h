@@ -65,6 +65,10 @@ typedef struct bz_engine *bz_handle;
 #define BZ_OPT_PROFILE 6       /* 1 = record HIP events between the kernels of every run (bz_slot_timing's ms[]); off by
                                   default: each event costs ~6 us of idle GPU between two kernels */
 
+#define BZ_OPT_GZ_LEVEL 7      /* zlib level 1..9 of the gzip members bz_assign_files writes (set on engines[0]); default 4.  The
+                                  reference compresses at 9 (gzip.compress, read_assignment.py:244-245): 3.7 % smaller files,
+                                  14x the CPU time per thread.  Only the decompressed stream is comparable (mtime in the header). */
+
 /* result flags (per row) */
 #define BZ_F_EXACT 1u      /* took the exact-match shortcut */
 #define BZ_F_BLANK 2u      /* empty putative_bc (`not row.putative_bc`, read_assignment.py:61) */

@@ -143,8 +143,8 @@ struct bz_engine {
     uint32_t *d_planes32 = nullptr;    // hi-plane | lo-plane << 16 per barcode (verify gather)
     int32_t *d_bucket = nullptr;       // bucket table over the sorted codes' top bits
     uint2 *d_bucket8 = nullptr;        //   and its one-gather form (k_classify_packed)
-    int32_t *d_seed_tab[2] = {nullptr, nullptr};      // seed index, plan 0: pieces 5|5|6 (max_ed 2), plan 1: 8|8 (max_ed <= 1)
-    int32_t *d_seed_members[2] = {nullptr, nullptr};  // per piece n_wl barcode indices grouped by the piece's code
+    int32_t *d_seed_tab[3] = {nullptr, nullptr, nullptr};      // seed index, plan 0: pieces 5|5|6 (max_ed 2), plan 1: 8|8 (max_ed <= 1), plan 2: 4|4|4|4 (max_ed 3)
+    int32_t *d_seed_members[3] = {nullptr, nullptr, nullptr};  // per piece n_fast barcode indices grouped by the piece's code
     uint32_t *d_pair_bitmap = nullptr;  // pair-seed index: 6 x 65536-bit bucket occupancy (k_pair_candidates)
     int32_t *d_pair_tab = nullptr;      //   6 CSR tables over the 16-bit key (piece a code << 8 | piece b code)
     uint2 *d_pair_members = nullptr;    //   6 x n_wl {barcode index, planes32} grouped by key, index order inside a bucket
@@ -203,7 +203,7 @@ void free_whitelist(bz_handle h) {
     h->d_hist_partial = nullptr;
     hipFree(h->d_grams); hipFree(h->d_planes32); hipFree(h->d_bucket); hipFree(h->d_bucket8);
     h->d_grams = nullptr; h->d_planes32 = nullptr; h->d_bucket = nullptr; h->d_bucket8 = nullptr;
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
         hipFree(h->d_seed_tab[k]); hipFree(h->d_seed_members[k]);
         h->d_seed_tab[k] = nullptr; h->d_seed_members[k] = nullptr;
     }
@@ -342,7 +342,7 @@ template <int K>
 void launch_scan_seeded(bz_handle h, Slot &s) {
     const int block = 256;
     const int grid = (int)((s.n + block - 1) / block);
-    const int plan = K == 2 ? 0 : 1;
+    const int plan = K == 2 ? 0 : K == 3 ? 2 : 1;
     hipLaunchKernelGGL(bz::k_scan_seeded<K>, dim3(grid), dim3(block), 0, s.stream, h->d_seed_tab[plan], h->d_seed_members[plan],
                        h->d_planes32, (int)h->n_fast, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_redo,
                        s.d_counters + 2, s.d_hit, s.d_ed, s.d_end, s.d_flags);
@@ -432,11 +432,10 @@ int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed
     }
     if (prof) HIP_TRY(hipEventRecord(s.ev[1], s.stream));
     if (h->wl_regular && !h->force_generic && max_ed <= bz::kMaxK) {
-        // product path for max_ed <= 2: pigeonhole seeds + verify (BZ_OPT_SCAN_MODE 0); mode 2 = exact 3-gram
-        // filter + verify over the whole whitelist; mode 1 = brute force (also what max_ed 3 takes: its
-        // seeds and 3-gram sets are too weak to pay)
+        // product path: pigeonhole seeds + verify (BZ_OPT_SCAN_MODE 0; max_ed 3: four 4-nt pieces); mode 2 = exact 3-gram
+        // filter + verify over the whole whitelist (max_ed <= 2; its sets are too weak for 3); mode 1 = brute force
         // (event words hold the barcode index in 25 bits: larger whitelists take the filtered scan)
-        const bool seeded = (h->scan_mode == 0 || h->scan_mode == 3) && max_ed <= 2 && h->n_fast < ((int64_t)1 << 25);
+        const bool seeded = (h->scan_mode == 0 || h->scan_mode == 3) && h->n_fast < ((int64_t)1 << 25);
         const bool filtered = !seeded && h->scan_mode != 1 && max_ed <= 2;
         switch (max_ed) {
             case 0: if (seeded) launch_scan_seeded<0>(h, s); else if (filtered) launch_scan_filtered<0>(h, s); else launch_scan<0>(h, s); break;
@@ -446,7 +445,7 @@ int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed
                         else launch_pair_stream(h, s);
                     } else if (seeded) launch_scan_seeded<2>(h, s);
                     else if (filtered) launch_scan_filtered<2>(h, s); else launch_scan<2>(h, s); break;
-            default: launch_scan<3>(h, s); break;
+            default: if (seeded) launch_scan_seeded<3>(h, s); else launch_scan<3>(h, s); break;
         }
         HIP_TRY(hipGetLastError());
     }
@@ -700,9 +699,9 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
         h->n_blk = (int)n_blk;
 
         // seed index (k_scan_seeded): per piece a CSR bucket table over the piece's 2-bit code
-        const int plan_n[2] = {3, 2};
-        const int plan_len[2][3] = {{5, 5, 6}, {8, 8, 0}}, plan_off[2][3] = {{0, 5, 10}, {0, 8, 0}};
-        for (int pl = 0; pl < 2; ++pl) {
+        const int plan_n[3] = {3, 2, 4};
+        const int plan_len[3][4] = {{5, 5, 6, 0}, {8, 8, 0, 0}, {4, 4, 4, 4}}, plan_off[3][4] = {{0, 5, 10, 0}, {0, 8, 0, 0}, {0, 4, 8, 12}};
+        for (int pl = 0; pl < 3; ++pl) {
             size_t tab_size = 0;
             for (int q = 0; q < plan_n[pl]; ++q) tab_size += ((size_t)1 << (2 * plan_len[pl][q])) + 1;
             std::vector<int32_t> tab(tab_size), mem((size_t)plan_n[pl] * nf);

@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void k_scan_filtered(
 // share one piece with one of those <= 9 text windows is a SUPERSET of {w : sub_ed(w, T) <= K}; a
 // barcode outside it can never enter the reference's fold (read_assignment.py:73-85).
 //
-// Plan per K (SeedPlan): K = 2 -> pieces 5|5|6 nt (1024 / 1024 / 4096 buckets); K <= 1 -> 8|8 nt
+// Plan per K (SeedPlan): K = 3 -> 4|4|4|4 nt (256 buckets each, below); K = 2 -> pieces 5|5|6 nt (1024 / 1024 / 4096 buckets); K <= 1 -> 8|8 nt
 // (65536 buckets each; sound for K = 0 too).  The host builds, per piece, a bucket table over the
 // piece's 2-bit code (CSR: tab[code] .. tab[code+1] into `members`, barcode indices).  For a 5k
 // whitelist a read meets ~100 candidates instead of 5000 pairs.
@@ -446,14 +446,35 @@ __global__ __launch_bounds__(256) void k_scan_filtered(
 // and the reference's order-dependent fold is replayed over the lane's events sorted by whitelist
 // index (duplicates dropped) at the end.  A lane with more than kMaxEvents events is not folded
 // here: its row goes to `redo_list` and the order-preserving k_scan_filtered finishes it.
-constexpr int kSeedShifts = 9;                                    // text windows per piece: o-2 .. o+6
+// K = 3 (--max-edit-distance 3, parser.py:100): four 4-nt pieces, one of them untouched by <= 3 operations.  The window
+// bound generalises: a piece at barcode offset o starts at text column j = s + o + d with s >= 0 the start of the match and
+// d >= -K the net indel shift in front of the piece, so j >= o - K; the match (length 16 + ins - del) must end inside 20
+// columns, s <= 4 - ins + del, hence j <= 4 + o + (deletions behind the piece) <= o + 4 + K.  K = 3: 11 windows per piece,
+// 44 probes of 256-bucket tables: ~860 candidates per read of a 5k-cell list instead of 5000 pairs.
 constexpr int kMaxEvents = 8;
-constexpr int kSeedBurst = 2 * kSeedShifts;                       // most FIFO pushes per step
 
 template <int K> struct SeedPlan;
-template <> struct SeedPlan<2> { static constexpr int n = 3; static constexpr int len[3] = {5, 5, 6}; static constexpr int off[3] = {0, 5, 10}; };
-template <> struct SeedPlan<1> { static constexpr int n = 2; static constexpr int len[3] = {8, 8, 0}; static constexpr int off[3] = {0, 8, 0}; };
+template <> struct SeedPlan<2> {
+    static constexpr int n = 3, shifts = 9, first = -2;
+    static constexpr int len(int p) { return p == 2 ? 6 : 5; }
+    static constexpr int off(int p) { return 5 * p; }
+};
+template <> struct SeedPlan<1> {
+    static constexpr int n = 2, shifts = 9, first = -2;
+    static constexpr int len(int) { return 8; }
+    static constexpr int off(int p) { return 8 * p; }
+};
 template <> struct SeedPlan<0> : SeedPlan<1> {};
+template <> struct SeedPlan<3> {
+    static constexpr int n = 4, shifts = 11, first = -3;
+    static constexpr int len(int) { return 4; }
+    static constexpr int off(int p) { return 4 * p; }
+};
+template <class Plan> constexpr int seed_tab_base(int p) {       // where piece p's CSR table starts inside the plan's table
+    int b = 0;
+    for (int q = 0; q < p; ++q) b += (1 << (2 * Plan::len(q))) + 1;
+    return b;
+}
 
 template <int K>
 __global__ __launch_bounds__(256) void k_scan_seeded(
@@ -464,6 +485,14 @@ __global__ __launch_bounds__(256) void k_scan_seeded(
     int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
     using Plan = SeedPlan<K>;
     __shared__ uint32_t fifo[kQCap][256];
+    // The fold (read_assignment.py:73-85) consumes at most TWO events of each distance class, always the first two in
+    // whitelist order (a class is dead for good once best_ed has dropped below it): slots 2c and 2c + 1 keep the two
+    // smallest events of class c (event word = index << 7 | ed << 5 | end, so words of one class order by index).
+    // However many near matches a row has -- at max_ed 3 a 5k-cell list gives most rows several -- 2 (K + 1) slots
+    // decide it, and nothing overflows.  (The first form kept the first 8 events met and handed the row to the ordered
+    // scan at the ninth: at max_ed 3 that was most rows, each a whole-whitelist pass.)
+    constexpr int kSlots = 2 * (K + 1);
+    static_assert(kSlots <= kMaxEvents, "event slots");
     __shared__ uint32_t events[kMaxEvents][256];
     const int n_list = *n_list_ptr;
     const int tid = threadIdx.x;
@@ -472,6 +501,8 @@ __global__ __launch_bounds__(256) void k_scan_seeded(
     const bool active = slot < n_list;
     const int r = list[active ? slot : n_list - 1];
     const int len = ext_len[r];
+#pragma unroll
+    for (int a = 0; a < kSlots; ++a) events[a][tid] = 0xFFFFFFFFu;
 
     uint32_t XH[kTextCols], XL[kTextCols];
     uint64_t tc = 0;                                              // 2-bit codes of the text, column j at bits 2j
@@ -488,9 +519,8 @@ __global__ __launch_bounds__(256) void k_scan_seeded(
     }
     const uint32_t one = in_vgpr(kOne2);
     uint32_t head = 0, tail = 0;
-    int nev = 0;
-    bool overflow = false;
     constexpr int kFirst = kBcLen - K - 1;
+    const bool full_text = len == kTextCols;
 
     // one verify round: every lane pops up to two candidates (oldest first) and runs the packed automaton
     auto verify_round = [&]() {
@@ -506,50 +536,65 @@ __global__ __launch_bounds__(256) void k_scan_seeded(
         const uint32_t bh = (p0 & 0xFFFFu) | (p1 << 16), bl = (p0 >> 16) | (p1 & 0xFFFF0000u);
         PackedScan<K> A;
         A.init();
-        uint32_t H = 0, P = 0;
+        uint32_t H[K + 1], P[K + 1];                              // accept bits per level, two columns per op
+#pragma unroll
+        for (int d = 0; d <= K; ++d) { H[d] = 0; P[d] = 0; }
 #pragma unroll
         for (int j = 0; j < kTextCols; ++j) {
             const uint32_t eq = BZ_LUT3(bh ^ XH[j], bl, XL[j], kTA & (kTB ^ kTC));
             if (j == kTextCols - 1) A.template step<true>(eq, one);
             else A.template step<false>(eq, one);
             if (j >= kFirst) {
-                if (((j - kFirst) & 1) == 0) P = A.R[K];
-                else H = BZ_LUT3(H, P, A.R[K], kTA | kTB | kTC);
+#pragma unroll
+                for (int d = 0; d <= K; ++d) {
+                    if (((j - kFirst) & 1) == 0) P[d] = A.R[d];
+                    else H[d] = BZ_LUT3(H[d], P[d], A.R[d], kTA | kTB | kTC);
+                }
             }
         }
-        if (((kTextCols - 1 - kFirst) & 1) == 0) H |= P;
-        uint32_t cand = ((H >> 15) & 1u) | ((H >> 30) & 2u);
+        if (((kTextCols - 1 - kFirst) & 1) == 0) {
+#pragma unroll
+            for (int d = 0; d <= K; ++d) H[d] |= P[d];
+        }
+        uint32_t cand = ((H[K] >> 15) & 1u) | ((H[K] >> 30) & 2u);
         if (!have || !active) cand = 0;
         if (cnt < 2) cand &= 1u;
-        while (cand) {                                            // rare, divergent, exact
+        while (cand) {                                            // accepted candidates: a few per row at most
             const int k = __ffs(cand) - 1;
             cand &= cand - 1;
-            const uint32_t p = k ? p1 : p0;
-            int ed, end;
-            exact_pair<K>(p & 0xFFFFu, p >> 16, XH, XL, len, tie, ed, end);
+            const uint32_t sh = k ? 31u : 15u;
+            int ed = K, end = 0;
+            if (full_text) {
+                // on a 20-column text the lowest level that accepts in any column IS the edit distance (the minimum over
+                // all end positions); the end index is needed for the fold's winner only and is computed after the fold
+#pragma unroll
+                for (int d = K - 1; d >= 0; --d) if ((H[d] >> sh) & 1u) ed = d;
+            } else {                                              // padding columns could lower the level: exact, on the real columns
+                const uint32_t p = k ? p1 : p0;
+                exact_pair<K>(p & 0xFFFFu, p >> 16, XH, XL, len, tie, ed, end);
+            }
             if (ed <= K) {                                        // a barcode met through several seeds is recorded once
                 const uint32_t ev = ((k ? i1 : i0) << 7) | ((uint32_t)ed << 5) | (uint32_t)end;
-                bool seen = false;
-                for (int a = 0; a < nev; ++a) seen = seen || events[a][tid] == ev;
-                if (!seen) {
-                    if (nev < kMaxEvents) events[nev++][tid] = ev;
-                    else overflow = true;
-                }
+                const uint32_t lo = events[2 * ed][tid], hi = events[2 * ed + 1][tid];
+                if (ev < lo) { events[2 * ed][tid] = ev; events[2 * ed + 1][tid] = lo; }
+                else if (ev > lo && ev < hi) events[2 * ed + 1][tid] = ev;
             }
         }
     };
 
+    constexpr int kSeedShifts = Plan::shifts;                     // text windows per piece
+    constexpr int kSeedBurst = 2 * kSeedShifts;                   // most FIFO pushes per step
+    static_assert(kSeedBurst < kQCap, "a step's pushes must fit the FIFO");
 #pragma unroll 1
     for (int p = 0; p < Plan::n; ++p) {
-        constexpr int kBase1 = (1 << (2 * Plan::len[0])) + 1, kBase2 = kBase1 + (1 << (2 * Plan::len[1])) + 1;
-        const int lp = p == 0 ? Plan::len[0] : p == 1 ? Plan::len[1] : Plan::len[2];
-        const int op = p == 0 ? Plan::off[0] : p == 1 ? Plan::off[1] : Plan::off[2];
-        const int32_t *tp = tab + (p == 0 ? 0 : p == 1 ? kBase1 : kBase2);
+        const int lp = Plan::len(p);
+        const int op = Plan::off(p);
+        const int32_t *tp = tab + seed_tab_base<Plan>(p);
         const int32_t *mp = members + (size_t)p * n_wl;
         int cur[kSeedShifts], end[kSeedShifts];
 #pragma unroll
-        for (int d = 0; d < kSeedShifts; ++d) {                   // 9 windows, 18 independent gathers
-            const int j = op - 2 + d;
+        for (int d = 0; d < kSeedShifts; ++d) {                   // all windows' bucket bounds: independent gathers
+            const int j = op + Plan::first + d;
             cur[d] = 0; end[d] = 0;
             if (active && j >= 0 && j + lp <= len) {              // window inside the real text
                 const uint32_t code = (uint32_t)(tc >> (2 * j)) & ((1u << (2 * lp)) - 1u);
@@ -579,12 +624,8 @@ __global__ __launch_bounds__(256) void k_scan_seeded(
     while (__builtin_amdgcn_ballot_w64(tail != head) != 0) verify_round();
 
     if (!active) return;
-    if (overflow) {                                               // too many near matches: finish in whitelist order
-        redo_list[atomicAdd(n_redo, 1)] = r;
-        return;
-    }
-    // replay the reference's fold over the events in whitelist order (insertion sort, duplicates dropped)
-    for (int a = 1; a < nev; ++a) {
+    // replay the reference's fold over the kept events in whitelist order (insertion sort; empty slots sort last)
+    for (int a = 1; a < kSlots; ++a) {
         const uint32_t v = events[a][tid];
         int b = a - 1;
         while (b >= 0 && events[b][tid] > v) { events[b + 1][tid] = events[b][tid]; --b; }
@@ -592,12 +633,15 @@ __global__ __launch_bounds__(256) void k_scan_seeded(
     }
     int best = K, hit = kHitNone, hit_end = -1;
     bool done = false;
-    uint32_t prev = 0xFFFFFFFFu;
-    for (int a = 0; a < nev; ++a) {
+    for (int a = 0; a < kSlots; ++a) {
         const uint32_t v = events[a][tid];
-        if (v == prev) continue;
-        prev = v;
+        if (v == 0xFFFFFFFFu) break;
         fold_update((int)((v >> 5) & 3u), (int)(v & 31u), (int)(v >> 7), best, hit, hit_end, done);
+    }
+    if (full_text && hit >= 0) {                                  // the winner's end index (its ed is `best`)
+        const uint32_t p = planes32[hit];
+        int ed_w;
+        exact_pair<K>(p & 0xFFFFu, p >> 16, XH, XL, len, tie, ed_w, hit_end);
     }
     hit_out[r] = hit >= 0 ? hit : -1;
     ed_out[r] = (int8_t)best;

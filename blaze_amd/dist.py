@@ -290,6 +290,26 @@ def part_path(fastq_out, rank: int) -> str:
     return f"{stem}.part{rank:04d}" + ('.gz' if gz else '')
 
 
+def native_run_rank(putative_bc_csv, whitelsit_csv, max_ed, n_process, batchsize, restrand=True, device=None):
+    """What one rank does with its files in assign_read_sharded: the native device pipeline (bz_assign_files_from) on this
+    process's GPU, `csv_skip_rows` rows of the table skipped.  -> run_rank(fns, out, csv_skip_rows) = (assigned, seen)."""
+    from . import read_assignment as ra
+
+    def run_rank(fns, out, csv_skip_rows):
+        whitelist = []
+        with open(whitelsit_csv, 'r') as f:
+            for line in f:
+                whitelist.append(line.split('-')[0].strip())
+        ordered = list(set(whitelist))
+        dev = device if device is not None else ra._device_ids(None)[0]
+        eng = ra.get_engine(dev)
+        ra._ensure_whitelist(eng, ordered)
+        threads = max(1, min(int(n_process or 1), os.cpu_count() or 1, 256))
+        return ra._assign_files_native([eng], fns, putative_bc_csv, out, str(out).endswith('.gz'), restrand, max_ed, batchsize,
+                                       ra.DEVICE_BATCH_ROWS, threads, csv_skip_rows=csv_skip_rows)
+    return run_rank
+
+
 def assign_read_sharded(comm, fastq_fns, fastq_out, putative_bc_csv, whitelsit_csv, max_ed, n_process, batchsize,
                         restrand=True, device=None, count_reads=count_fastq_reads, run_rank=None):
     """assign_read (read_assignment.py:253-330) with the FASTQ files sharded over the ranks of `comm`, one process
@@ -309,18 +329,7 @@ def assign_read_sharded(comm, fastq_fns, fastq_out, putative_bc_csv, whitelsit_c
     skip = int(per_rank[:comm.rank].sum())
     part = part_path(fastq_out, comm.rank)
     if run_rank is None:
-        def run_rank(fns, out, csv_skip_rows):
-            whitelist = []
-            with open(whitelsit_csv, 'r') as f:
-                for line in f:
-                    whitelist.append(line.split('-')[0].strip())
-            ordered = list(set(whitelist))
-            dev = device if device is not None else ra._device_ids(None)[0]
-            eng = ra.get_engine(dev)
-            ra._ensure_whitelist(eng, ordered)
-            threads = max(1, min(int(n_process or 1), os.cpu_count() or 1, 256))
-            return ra._assign_files_native([eng], fns, putative_bc_csv, out, str(out).endswith('.gz'), restrand, max_ed, batchsize,
-                                           ra.DEVICE_BATCH_ROWS, threads, csv_skip_rows=csv_skip_rows)
+        run_rank = native_run_rank(putative_bc_csv, whitelsit_csv, max_ed, n_process, batchsize, restrand, device)
     demul, total = run_rank(fastq_fns[lo:hi], part, skip) if hi > lo else (0, 0)
     sums = place_parts(comm, fastq_out, part, extra_sums=(demul, total))
     return int(sums[0]), int(sums[1])

@@ -219,26 +219,35 @@ def test_native_configs3_shape_10nt_umi(tmp_path):
     assert (tmp_path / "n.fastq").read_bytes() == (tmp_path / "p.fastq").read_bytes()
 
 
-class _SoloComm:
-    """One rank of a pretend world, driven in sequence on the one GPU of the box: the other ranks' contributions to
-    the two sums are supplied by the test (no data-path collective exists to emulate)."""
+class _ThreadComm:
+    """The ranks of a pretend world as THREADS of this process on the box's one GPU: real barriers and real sums, so the
+    whole of dist.assign_read_sharded runs (read counts -> csv rows to skip -> device pipeline -> every rank placing its
+    own part); only the device section is serialised (one engine, calls on a handle are not re-entrant)."""
 
-    def __init__(self, rank, world, others):
-        self.rank, self.world, self.others, self.calls = rank, world, others, 0
-
-    def allreduce_sum_i64(self, arr):
-        a = np.asarray(arr, dtype=np.int64) + np.asarray(self.others[self.calls], dtype=np.int64)
-        self.calls += 1
-        return a
+    def __init__(self, rank, world, shared):
+        self.rank, self.world, self._s = rank, world, shared
 
     def barrier(self):
-        pass
+        self._s["bar"].wait()
+
+    def allreduce_sum_i64(self, arr):
+        a = np.asarray(arr, dtype=np.int64)
+        with self._s["lock"]:
+            self._s["acc"] = self._s.get("acc", 0) + a
+        self._s["bar"].wait()
+        out = self._s["acc"].copy()
+        self._s["bar"].wait()
+        if self.rank == 0:
+            self._s.pop("acc")
+        self._s["bar"].wait()
+        return out
 
 
 @pytest.mark.parametrize("gz", [False, True])
 def test_file_shards_concatenate_to_the_single_run(tmp_path, gz):
     """Reads sharded by FILE over ranks (dist.assign_read_sharded -> bz_assign_files_from with the csv rows of the
-    earlier files skipped): the ranks' parts, concatenated in rank order, are the single-process output."""
+    earlier files skipped, every rank placing its own part at its offset): the output is the single-process output."""
+    import threading
     from blaze_amd import dist
     n = 5000
     fns, pc, pw, bounds = _make_files(tmp_path, n, 400, seed=91, n_files=4)
@@ -249,20 +258,30 @@ def test_file_shards_concatenate_to_the_single_run(tmp_path, gz):
     per_file = [dist.count_fastq_reads(f) for f in fns]
     assert per_file == [hi - lo for lo, hi in zip(bounds[:-1], bounds[1:])]          # incl. the gzipped one
     world = 3
-    spans = dist.partition_files([os.path.getsize(f) for f in fns], world)
-    per_rank = [sum(per_file[lo:hi]) for lo, hi in spans]
     out = str(tmp_path / ("sharded" + suffix))
-    parts, sums = [], np.zeros(2, np.int64)
-    for rank in range(1, world):                       # ranks 1.. first: rank 0 merges, so it goes last
-        others = np.array(per_rank); others[rank] = 0
-        comm = _SoloComm(rank, world, [others, np.zeros(2, np.int64)])
-        d, t = dist.assign_read_sharded(comm, fns, out, n_process=4, device=0, **kw)
-        parts.append((d, t))
-        sums += (d, t)
-        assert os.path.exists(dist.part_path(out, rank))
-    others = np.array(per_rank); others[0] = 0
-    comm = _SoloComm(0, world, [others, sums.copy()])
-    d, t = dist.assign_read_sharded(comm, fns, out, n_process=4, device=0, **kw)
+    shared = {"bar": threading.Barrier(world), "lock": threading.Lock()}
+    device_lock = threading.Lock()
+    native = dist.native_run_rank(pc, pw, 2, 4, 300, True, 0)
+
+    def run_rank(files, part, skip):
+        with device_lock:
+            return native(files, part, skip)
+    res, errs = {}, []
+
+    def rank_main(rank):
+        try:
+            res[rank] = dist.assign_read_sharded(_ThreadComm(rank, world, shared), fns, out, n_process=4, device=0, run_rank=run_rank, **kw)
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+            shared["bar"].abort()
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t_ in ts:
+        t_.start()
+    for t_ in ts:
+        t_.join(300)
+    assert not errs, errs
+    assert all(res[r] == (int(demul), int(total)) for r in range(world)) and int(total) == n
+    d, t = res[0]
     assert (d, t) == (int(demul), int(total)) and t == n
     assert _text(out) == _text(whole)
     if not gz:

@@ -90,10 +90,15 @@ def _recv_exact(sock, n):
 class Hub:
     """Host-side plumbing between the ranks of one node: rank 0 listens on MASTER_ADDR:(MASTER_PORT + 1)
     (BLAZE_AMD_RDZV_PORT overrides; MASTER_PORT itself belongs to the launcher's store), the others connect.
+    If that port is taken rank 0 moves on to the next of PORT_TRIES consecutive ports; a client tells the hub from
+    whatever else may listen there by a handshake that carries the job's key (MASTER_ADDR, MASTER_PORT, run id).
     It carries the 128-byte RCCL id, and -- when RCCL cannot be initialised -- the barrier / max / sum of a few scalars.
     Never the data path.  Sockets die with their processes: nothing stale survives a crashed job."""
+    PORT_TRIES = 16
+    MAGIC = b"BZHUB1"
 
     def __init__(self, rank, world, addr=None, port=None, timeout_s=120.0):
+        import hashlib
         import socket
         import struct
         self.rank, self.world, self._struct = rank, world, struct
@@ -102,40 +107,69 @@ class Hub:
             return
         addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
         port = int(port or os.environ.get("BLAZE_AMD_RDZV_PORT") or int(os.environ.get("MASTER_PORT", "29500")) + 1)
-        self.endpoint = f"{addr}:{port}"
-        self.peers = {}
+        hello = self.MAGIC + hashlib.sha1(f"{_rendezvous_key()}|{world}".encode()).digest()[:10]
         io_timeout = float(os.environ.get("BLAZE_AMD_HUB_TIMEOUT", "1800"))
         if rank == 0:
-            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            try:
-                srv.bind((addr, port))
-            except OSError:
-                srv.bind(("", port))                  # MASTER_ADDR is a name that is not an address of this host
-            srv.listen(max(world, 1))
-            srv.settimeout(timeout_s)
+            srv = None
+            for k in range(self.PORT_TRIES):
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    try:
+                        srv.bind((addr, port + k))
+                    except socket.gaierror:
+                        srv.bind(("", port + k))      # MASTER_ADDR is a name that does not resolve here
+                    port += k
+                    break
+                except OSError:
+                    srv.close()
+                    srv = None
+            if srv is None:
+                raise OSError(f"rendezvous hub: none of the ports {port}..{port + self.PORT_TRIES - 1} can be bound")
+            self.endpoint = f"{addr}:{port}"
+            srv.listen(max(world, 8))
+            deadline = time.time() + timeout_s
             while len(self.peers) < world - 1:
+                srv.settimeout(max(0.1, deadline - time.time()))
                 c, _ = srv.accept()
+                try:
+                    c.settimeout(5.0)
+                    if _recv_exact(c, len(hello)) != hello:
+                        raise ConnectionError("not one of this job's ranks")
+                    r = struct.unpack("<i", _recv_exact(c, 4))[0]
+                    if not 0 < r < world or r in self.peers:
+                        raise ConnectionError(f"unexpected rank {r}")
+                    c.sendall(b"BZOK")
+                except (OSError, ConnectionError):
+                    c.close()
+                    continue
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 c.settimeout(io_timeout)
-                r = struct.unpack("<i", _recv_exact(c, 4))[0]
                 self.peers[r] = c
             srv.close()
         else:
             deadline = time.time() + timeout_s
+            k = 0
             while True:
                 c = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                c.settimeout(5.0)
                 try:
-                    c.connect((addr, port))
+                    c.connect((addr, port + k))
+                    c.sendall(hello + struct.pack("<i", rank))
+                    if _recv_exact(c, 4) != b"BZOK":
+                        raise ConnectionError("no hub behind this port")
+                    port += k
                     break
-                except OSError:
+                except (OSError, ConnectionError):
                     c.close()
                     if time.time() > deadline:
-                        raise TimeoutError(f"rank {rank}: no rendezvous hub at {addr}:{port} after {timeout_s}s")
-                    time.sleep(0.05)
+                        raise TimeoutError(f"rank {rank}: no rendezvous hub at {addr}:{port}..{port + self.PORT_TRIES - 1} after {timeout_s}s")
+                    k = (k + 1) % self.PORT_TRIES
+                    if k == 0:
+                        time.sleep(0.05)
+            self.endpoint = f"{addr}:{port}"
             c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             c.settimeout(io_timeout)
-            c.sendall(struct.pack("<i", rank))
             self.peers[0] = c
 
     def _send(self, sock, payload):

@@ -188,6 +188,40 @@ def test_hub_allgather_three_ranks():
         assert c == bytes(range(128))
 
 
+def test_hub_moves_past_a_taken_port_and_ignores_strangers(monkeypatch):
+    """MASTER_PORT + 1 already belongs to something else: rank 0 binds the next port, the clients find it by the
+    handshake (the foreign listener never answers it), and a stranger that connects to the hub is dropped."""
+    import threading
+    from blaze_amd import dist
+    monkeypatch.setenv("MASTER_PORT", "0")
+    foreign = socket.socket()
+    foreign.bind(("127.0.0.1", 0))
+    foreign.listen(4)
+    port = foreign.getsockname()[1]
+    got = {}
+
+    def rank_main(r):
+        hub = dist.Hub(r, 2, addr="127.0.0.1", port=port, timeout_s=40)
+        got[r] = (hub.endpoint, hub.allgather(r * 10))
+        hub.close()
+    t0 = threading.Thread(target=rank_main, args=(0,))
+    t0.start()
+    import time
+    time.sleep(0.3)
+    stranger = socket.socket()
+    try:
+        stranger.connect(("127.0.0.1", port + 1))
+        stranger.sendall(b"GET / HTTP/1.0\r\n\r\n and some more bytes")
+    except OSError:
+        pass
+    t1 = threading.Thread(target=rank_main, args=(1,))
+    t1.start()
+    t0.join(60), t1.join(60)
+    stranger.close(), foreign.close()
+    assert got[0][1] == [0, 10] and got[1][1] == [0, 10]
+    assert got[0][0] == got[1][0] and not got[0][0].endswith(f":{port}")
+
+
 def _run_bench(args, env_extra, timeout=300):
     env = dict(os.environ, BLAZE_AMD_BENCH_ENGINE="tests.stub_engine:StubEngine", PYTHONPATH=ROOT, **env_extra)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):

@@ -24,7 +24,7 @@ EXPORTS = [
     "bz_assign_run", "bz_assign_fetch", "bz_slot_sync", "bz_slot_timing", "bz_sub_edit_distance",
     "bz_edit_distance", "bz_counts_reset", "bz_counts_get", "bz_comm_unique_id", "bz_comm_init",
     "bz_comm_allreduce_counts", "bz_comm_allreduce_f64", "bz_comm_destroy", "bz_valu_peak_probe", "bz_assign_files", "bz_far_from_all", "bz_putative_bc",
-    "bz_putative_bc_files", "bz_assign_files_from", "bz_fastq_count_reads", "bz_assign_device_noalloc", "bz_comm_allreduce_i64", "bz_host_alloc", "bz_host_free", "bz_assign_submit_pinned",
+    "bz_putative_bc_files", "bz_assign_files_from", "bz_fastq_count_reads", "bz_assign_device_noalloc", "bz_comm_allreduce_i64", "bz_host_alloc", "bz_host_free", "bz_assign_submit_pinned", "bz_gzip_fastq_bound", "bz_gzip_fastq_member",
 ]
 
 
@@ -74,6 +74,8 @@ def load():
         "bz_comm_allreduce_i64": ([p, p, i64], i),
         "bz_host_alloc": ([ctypes.POINTER(p), i64], i),
         "bz_host_free": ([p], i),
+        "bz_gzip_fastq_bound": ([i64], i64),
+        "bz_gzip_fastq_member": ([cp, i64, p, i64, ctypes.POINTER(i64)], i),
         "bz_assign_submit_pinned": ([p, i, p, i, p, p, p, i64, i, p, p, p, p], i),
         "bz_comm_destroy": ([p], i),
         "bz_valu_peak_probe": ([p, i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_float)], i),

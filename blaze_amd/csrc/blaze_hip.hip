@@ -128,7 +128,7 @@ static std::mutex g_scratch_mu;
 
 struct bz_engine {
     int device = 0;
-    int tie_rule = 0, shortcut = 1, force_generic = 0, scan_mode = 0, pair_fused = 0, profile = 0, gz_level = 4;
+    int tie_rule = 0, shortcut = 1, force_generic = 0, scan_mode = 0, pair_fused = 0, profile = 0, gz_level = 0;
     // whitelist
     int64_t n_wl = -1;
     int wl_regular = 0;                 // the packed fast path is usable (every entry 16-nt ACGT, or all but a few: `mixed`)
@@ -569,7 +569,7 @@ int bz_set_option(bz_handle h, int option, int64_t value) {
         case BZ_OPT_SCAN_MODE: if (value < 0 || value > 3) return fail(BZ_E_ARG, "scan mode must be 0..3"); h->scan_mode = (int)value; return BZ_OK;
         case BZ_OPT_PAIR_FUSED: h->pair_fused = value ? 1 : 0; return BZ_OK;
         case BZ_OPT_PROFILE: h->profile = value ? 1 : 0; return BZ_OK;
-        case BZ_OPT_GZ_LEVEL: if (value < 1 || value > 9) return fail(BZ_E_ARG, "gz level must be 1..9"); h->gz_level = (int)value; return BZ_OK;
+        case BZ_OPT_GZ_LEVEL: if (value < 0 || value > 9) return fail(BZ_E_ARG, "gz level must be 0..9"); h->gz_level = (int)value; return BZ_OK;
     }
     return fail(BZ_E_ARG, "unknown option %d", option);
 }
@@ -1272,14 +1272,14 @@ int bz_assign_files_from(bz_handle *engines, int n_engines, const char *const *f
     job.gz = gz != 0; job.restrand = restrand != 0; job.max_ed = max_ed; job.batch_size = batch_size;
     job.n_threads = n_threads; job.device_batch_rows = std::min<int64_t>(device_batch_rows, (int64_t)1 << 24);
     job.csv_skip_rows = csv_skip_rows;
-    // zlib level of the `.gz` members.  The reference's gzip.compress uses 9; the decompressed stream is the contract (the
-    // compressed bytes carry a wall-clock mtime and are never reproducible).  Default 4: on FASTQ text level 9
-    // is 3.7 % smaller and 14x slower per host thread (profiles/r02e_gz_perf.txt); BZ_OPT_GZ_LEVEL / BLAZE_AMD_GZ_LEVEL=9
-    // give the reference's setting back.
+    // How the `.gz` members are compressed.  The reference's gzip.compress is zlib level 9; the decompressed stream is the
+    // contract (the compressed bytes carry a wall-clock mtime and are never reproducible).  Default 0 = the
+    // FASTQ-aware block encoder of fastq_deflate.h (1.8 % larger than level 9, ~30x faster per host thread); 1..9 = zlib
+    // at that level (BZ_OPT_GZ_LEVEL / BLAZE_AMD_GZ_LEVEL=9 give the reference's setting back).
     job.gz_level = engines[0]->gz_level;
     if (const char *lv = getenv("BLAZE_AMD_GZ_LEVEL")) {
         const int v = atoi(lv);
-        if (v >= 1 && v <= 9) job.gz_level = v;
+        if (v >= 0 && v <= 9 && (v > 0 || lv[0] == '0')) job.gz_level = v;
     }
 
     struct Queue {                                   // reader thread -> main thread, depth 2
@@ -1626,6 +1626,24 @@ int bz_putative_bc_files(bz_handle *engines, int n_engines, const char *const *f
         out_counts[6] = n_chunks;
     }
     return rc;
+}
+
+// One gzip member of `text` by the FASTQ-aware block encoder (host only; what bz_assign_files writes per batch at gz level 0).
+int64_t bz_gzip_fastq_bound(int64_t n) { return n < 0 ? -1 : 2 * n + 1024 + (n / 32) * 520; }
+
+int bz_gzip_fastq_member(const char *text, int64_t n, uint8_t *out, int64_t cap, int64_t *out_len) {
+    if (n < 0 || (n > 0 && !text) || !out || !out_len) return fail(BZ_E_ARG, "bad gzip arguments");
+    if (n >= (int64_t)1 << 32) return fail(BZ_E_LIMIT, "a gzip member holds less than 4 GiB of text");
+    std::string z;
+    try {
+        fqz::gzip_fastq_member(text, (size_t)n, z);
+    } catch (const std::exception &e) {
+        return fail(BZ_E_ARG, "%s", e.what());
+    }
+    if ((int64_t)z.size() > cap) return fail(BZ_E_LIMIT, "output needs %lld bytes, %lld given", (long long)z.size(), (long long)cap);
+    memcpy(out, z.data(), z.size());
+    *out_len = (int64_t)z.size();
+    return BZ_OK;
 }
 
 int bz_valu_peak_probe(bz_handle h, int iters, double *lane_ops_per_s, float *ms_out) {

@@ -25,6 +25,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include "fastq_deflate.h"
 
 #include <array>
 #include <atomic>
@@ -301,7 +302,7 @@ struct Job {
     std::vector<std::string> fastq_fns;
     std::string csv, out_path;
     bool gz = false, restrand = true;
-    int max_ed = 2, batch_size = 1000, n_threads = 8, gz_level = 4;
+    int max_ed = 2, batch_size = 1000, n_threads = 8, gz_level = 0;   // gz_level: 0 = fastq_deflate.h, 1..9 = zlib
     int64_t device_batch_rows = 1 << 16;
     int64_t csv_skip_rows = 0;               // rows of the table that belong to reads of earlier FASTQ files (another rank's)
 };
@@ -582,7 +583,10 @@ inline void format_batch(Chunk &ch, int b, const Job &job, const std::vector<cha
         text.push_back('\n');
     }
     ch.demul[b] = demul;
-    if (job.gz) gzip_member(text, ch.out[b], job.gz_level);   // one member per batch, also when empty (gzip.compress(b''))
+    if (job.gz) {                                               // one member per batch, also when empty (gzip.compress(b''))
+        if (job.gz_level == 0) fqz::gzip_fastq_member(text.data(), text.size(), ch.out[b]);   // FASTQ-aware blocks (fastq_deflate.h)
+        else gzip_member(text, ch.out[b], job.gz_level);                                     // zlib at the given level
+    }
     else ch.out[b].swap(text);
 }
 

@@ -61,3 +61,16 @@ def fastq_parser(file_handle):
         next(file_handle)          # '+'
         qual = next(file_handle)
         yield read_tuple(title[1:].split()[0], seq.strip(), qual.strip())
+
+
+def gzip_fastq_member(text: bytes) -> bytes:
+    """One gzip member of `text` by the native FASTQ-aware deflate encoder (what the native host writes per batch;
+    replaces gzip.compress(out_buffer.encode()), read_assignment.py:244-245: same decompressed bytes).  Host only."""
+    import ctypes
+    from . import _lib
+    L = _lib.load()
+    cap = L.bz_gzip_fastq_bound(len(text))
+    out = ctypes.create_string_buffer(int(cap))
+    n = ctypes.c_int64(0)
+    _lib.check(L.bz_gzip_fastq_member(text, len(text), out, cap, ctypes.byref(n)))
+    return out.raw[:n.value]

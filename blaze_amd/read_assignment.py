@@ -273,8 +273,9 @@ def assign_read(fastq_fns=None, fastq_out=None, putative_bc_csv=None,
     from the GPUs in `devices` (default: $BLAZE_AMD_DEVICES, else $LOCAL_RANK, else GPU 0).
     host="native" (default) runs the batch loop in C++ (bz_assign_files); host="python" runs the
     pandas mirror of the reference's loop below.  Both give the same bytes (of a `.gz` output: the same DECOMPRESSED
-    bytes; the native host compresses its members at zlib level `gz_level`, default 4 -- the reference's level 9
-    makes files 3.7 % smaller at 14x the CPU time; $BLAZE_AMD_GZ_LEVEL overrides both).
+    bytes; the native host writes its members with a FASTQ-aware deflate encoder, `gz_level` 1..9 selects zlib at that
+    level instead -- the reference's level 9 makes files 1.8 % smaller at ~30x the CPU time, see INTEGRATION.md section 5;
+    $BLAZE_AMD_GZ_LEVEL overrides both).
     Returns (reads assigned, reads seen)."""
     if args:
         fastq_fns = args.fastq_fns
@@ -300,7 +301,7 @@ def assign_read(fastq_fns=None, fastq_out=None, putative_bc_csv=None,
         _ensure_whitelist(eng, ordered)
     if host == "native":
         threads = max(1, min(int(n_process or 1), os.cpu_count() or 1, 256))
-        engines[0].set_option(_lib.BZ_OPT_GZ_LEVEL, int(gz_level) if gz_level else 4)
+        engines[0].set_option(_lib.BZ_OPT_GZ_LEVEL, int(gz_level) if gz_level else 0)
         out = _assign_files_native(engines, fastq_fns, putative_bc_csv, fastq_out, gz, restrand, max_ed, batchsize,
                                    device_batch_rows, threads)
         logger.info(helper.green_msg(f"Reads assignment completed. Demultiplexed read saved in {fastq_out}!", printit=False))

@@ -65,9 +65,11 @@ typedef struct bz_engine *bz_handle;
 #define BZ_OPT_PROFILE 6       /* 1 = record HIP events between the kernels of every run (bz_slot_timing's ms[]); off by
                                   default: each event costs ~6 us of idle GPU between two kernels */
 
-#define BZ_OPT_GZ_LEVEL 7      /* zlib level 1..9 of the gzip members bz_assign_files writes (set on engines[0]); default 4.  The
-                                  reference compresses at 9 (gzip.compress, read_assignment.py:244-245): 3.7 % smaller files,
-                                  14x the CPU time per thread.  Only the decompressed stream is comparable (mtime in the header). */
+#define BZ_OPT_GZ_LEVEL 7      /* how bz_assign_files compresses its gzip members (set on engines[0]): 0 (default) = the FASTQ-aware
+                                  block encoder (blaze_amd/csrc/fastq_deflate.h: every sequence line and everything between two
+                                  sequence lines as its own dynamic-Huffman block, no match search), 1..9 = zlib at that level.
+                                  The reference compresses at 9 (gzip.compress, read_assignment.py:244-245): 1.8 % smaller than
+                                  level 0, ~30x the CPU time.  Only the decompressed stream is comparable (mtime in the header). */
 
 /* result flags (per row) */
 #define BZ_F_EXACT 1u      /* took the exact-match shortcut */
@@ -242,6 +244,13 @@ int bz_comm_allreduce_f64(bz_handle h, double *inout, int n, int op); /* op 0 su
  * counts and part sizes of the file-sharded runs (blaze_amd/dist.py), which must not round-trip through doubles. */
 int bz_comm_allreduce_i64(bz_handle h, int64_t *inout, int64_t n);
 int bz_comm_destroy(bz_handle h);
+
+/* ---- the gzip member writer on its own (host only, no GPU needed) ------------------------------------- */
+/* One complete gzip member of `text` as bz_assign_files writes it per batch at gz level 0; replaces
+ * gzip.compress(out_buffer.encode()) of read_assignment.py:244-245 (same decompressed bytes).  `out` needs
+ * bz_gzip_fastq_bound(n) bytes at most. */
+int64_t bz_gzip_fastq_bound(int64_t n);
+int bz_gzip_fastq_member(const char *text, int64_t n, uint8_t *out, int64_t cap, int64_t *out_len);
 
 /* ---- measurement helper ------------------------------------------------------------------ */
 /* Independent-chain 32-bit integer VALU micro-kernel (v_and_or / v_lshl_or / v_or3 / v_xor mix):

@@ -76,3 +76,73 @@ def test_shard_ranges_cover_and_preserve_order():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- the FASTQ-aware gzip member writer (blaze_amd/csrc/fastq_deflate.h) through the C ABI: host only, no GPU ----------
+def _fastq_text(rng, n_reads, max_len=1500, odd=False):
+    import numpy as np
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = []
+    for k in range(n_reads):
+        L = int(rng.integers(0 if odd else 60, max_len))
+        seq = acgt[rng.integers(0, 4, L)].tobytes()
+        if odd and k % 3 == 0:
+            seq = seq.replace(b"A", b"N", 2).lower()
+        q = bytes(rng.integers(33, 90, L, dtype=np.uint8))
+        out.append(b"@ACGTACGTACGTACGT_TTTTGGGGAAAA#%08x-read_+\tCB:Z:ACGTACGTACGTACGT\tUB:Z:TTTTGGGGAAAA\n" % k + seq + b"\n+\n" + q + b"\n")
+    return b"".join(out)
+
+
+def test_gzip_fastq_member_round_trips():
+    """Python's gzip reads back exactly the text the native member writer was given: FASTQ-shaped members, records with
+    empty / very long / non-ACGT sequences, texts that are not FASTQ at all, and the empty member of an empty batch."""
+    import gzip
+    import numpy as np
+    from blaze_amd import helper
+    rng = np.random.default_rng(7)
+    texts = [b"", b"\n", b"A", b"@r\n\n+\n\n", _fastq_text(rng, 1), _fastq_text(rng, 300), _fastq_text(rng, 50, odd=True),
+             _fastq_text(rng, 3, max_len=200_000), bytes(rng.integers(0, 256, 100_000, dtype=np.uint8)), b"A" * 300_000,
+             b"@x\n" + b"ACGT" * 5000, b"\n" * 1000, bytes(range(256)) * 40]
+    sizes = []
+    for t in texts:
+        z = helper.gzip_fastq_member(t)
+        assert gzip.decompress(z) == t
+        sizes.append((len(t), len(z)))
+    # several members back to back are one gzip file (what assign_read writes: one member per batch)
+    z = b"".join(helper.gzip_fastq_member(t) for t in texts[4:7])
+    assert gzip.decompress(z) == b"".join(texts[4:7])
+    # and it is a compressor: FASTQ text with uniform qualities over 57 levels shrinks to about (2.25 + 5.9) / 16 of its size
+    n, zn = sizes[5]
+    assert zn < 0.56 * n, (n, zn)
+
+
+def test_gzip_fastq_member_hypothesis():
+    import gzip
+    from hypothesis import given, settings, strategies as st
+    from blaze_amd import helper
+
+    line = st.one_of(st.binary(max_size=200), st.text(alphabet="ACGTN", max_size=400).map(str.encode),
+                     st.text(alphabet="ACGT", min_size=48, max_size=300).map(str.encode))
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(line, max_size=40), st.booleans())
+    def check(lines, trailing_newline):
+        t = b"\n".join(lines) + (b"\n" if trailing_newline else b"")
+        assert gzip.decompress(helper.gzip_fastq_member(t)) == t
+    check()
+
+
+def test_gzip_member_crc_matches_zlib_on_edge_lengths():
+    """The carry-less-multiplication CRC-32 takes whole 16-byte chunks of texts of at least 64 bytes, zlib the rest:
+    lengths around every one of those edges, against zlib.crc32 (the trailer's CRC field) and against gzip itself."""
+    import gzip
+    import zlib
+    import numpy as np
+    from blaze_amd import helper
+    rng = np.random.default_rng(1)
+    for n in [0, 1, 15, 16, 63, 64, 65, 79, 80, 127, 128, 129, 143, 1000, 4095, 4096, 4097, 100003]:
+        t = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        z = helper.gzip_fastq_member(t)
+        assert gzip.decompress(z) == t
+        assert int.from_bytes(z[-8:-4], "little") == zlib.crc32(t), n
+        assert int.from_bytes(z[-4:], "little") == n

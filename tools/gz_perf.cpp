@@ -3,6 +3,7 @@
 // UMI tags, uniform ACGT sequence, nanopore-like qualities) and times deflate at several levels / match-chain limits
 // / strategies, on 1..T threads.     g++ -O2 -pthread tools/gz_perf.cpp -lz -o /tmp/gz_perf && /tmp/gz_perf [threads...]
 #include <zlib.h>
+#include "../blaze_amd/csrc/fastq_deflate.h"
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -39,7 +40,24 @@ static std::string make_member(int reads, uint64_t seed) {
 
 struct Cfg { const char *name; int level, chain, strategy; };
 
+static bool roundtrip_ok(const std::string &gzipped, const std::string &want) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    inflateInit2(&zs, 15 + 16);
+    std::string got(want.size() + 64, 0);
+    zs.next_in = (Bytef *)gzipped.data(); zs.avail_in = (uInt)gzipped.size();
+    zs.next_out = (Bytef *)&got[0]; zs.avail_out = (uInt)got.size();
+    const int rc = inflate(&zs, Z_FINISH);
+    const size_t n = zs.total_out;
+    inflateEnd(&zs);
+    return rc == Z_STREAM_END && n == want.size() && memcmp(got.data(), want.data(), n) == 0;
+}
+
 static size_t gz(const std::string &in, std::string &out, const Cfg &c) {
+    if (c.level < 0) {                              // the FASTQ-aware block encoder (blaze_amd/csrc/fastq_deflate.h)
+        fqz::gzip_fastq_member(in.data(), in.size(), out);
+        return out.size();
+    }
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     deflateInit2(&zs, c.level, Z_DEFLATED, 15 + 16, 8, c.strategy);
@@ -62,11 +80,20 @@ int main(int argc, char **argv) {
     size_t total = 0;
     for (int m = 0; m < n_members; ++m) { members.push_back(make_member(1000, 1000 + m)); total += members.back().size(); }
     printf("%d members of 1000 reads, %.1f MB of FASTQ text\n", n_members, total / 1e6);
+    {
+        std::string o;
+        int bad = 0;
+        for (const std::string &m : members) { fqz::gzip_fastq_member(m.data(), m.size(), o); bad += !roundtrip_ok(o, m); }
+        const std::string odd[] = {"", "\n", "A", "@x\nACGT\n+\nIIII\n", std::string(100000, 'A'), std::string("@r\n") + std::string(70000, 'N') + "\n+\n" + std::string(70000, '#') + "\n"};
+        for (const std::string &m : odd) { fqz::gzip_fastq_member(m.data(), m.size(), o); bad += !roundtrip_ok(o, m); }
+        printf("fastq blocks: zlib inflates every member back to its text: %s\n", bad ? "NO" : "yes");
+        if (bad) return 1;
+    }
     const Cfg cfgs[] = {{"level 9 (reference)", 9, 0, Z_DEFAULT_STRATEGY}, {"level 9, chain 256", 9, 256, Z_DEFAULT_STRATEGY},
                         {"level 9, chain 64", 9, 64, Z_DEFAULT_STRATEGY}, {"level 9, chain 16", 9, 16, Z_DEFAULT_STRATEGY},
                         {"level 6", 6, 0, Z_DEFAULT_STRATEGY}, {"level 5", 5, 0, Z_DEFAULT_STRATEGY}, {"level 4", 4, 0, Z_DEFAULT_STRATEGY},
                         {"level 3", 3, 0, Z_DEFAULT_STRATEGY}, {"level 2", 2, 0, Z_DEFAULT_STRATEGY}, {"level 1", 1, 0, Z_DEFAULT_STRATEGY},
-                        {"huffman only", 6, 0, Z_HUFFMAN_ONLY}, {"level 6 filtered", 6, 0, Z_FILTERED}};
+                        {"huffman only", 6, 0, Z_HUFFMAN_ONLY}, {"fastq blocks (ours)", -1, 0, 0}, {"level 6 filtered", 6, 0, Z_FILTERED}};
     for (const Cfg &c : cfgs) {
         for (int T : threads) {
             std::vector<size_t> outb(T, 0);

@@ -247,7 +247,7 @@ def main():
     full = synth.full_whitelist_codes(400_000, seed=1)       # stand-in pool for the 6.8M 10x list
     cells = synth.cell_whitelist_codes(a.cells, full, seed=2)
     rows = synth.make_rows(a.rows, cells, full, umi_len=12, seed=3 + 1000 * rank)
-    ext, el, bo, bl = synth.pack_ext(rows)
+    ext, el, bo, bl = synth.pack_ext(rows, stride=24)        # 24 B/row: the tightest packed layout for 20-nt extensions
     wl_ascii = synth.codes_to_bytes(cells)
     eng.set_whitelist_codes16(wl_ascii)
     eng.stage(0, ext, el, bo, bl)

@@ -416,7 +416,7 @@ int fold_totals(bz_handle h, hipStream_t st) {
 int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed, int32_t *next_counters, int32_t *publish) {
     const int n = (int)s.n;
     const bool prof = s.timed;
-    const bool packed = (s.stride & 15) == 0 && s.stride >= 32;
+    const bool packed = bz::packed_stride(s.stride);   // device buffers are hipMalloc'ed (256-byte aligned); bz_assign_device_noalloc checks the caller's
     if (prof) HIP_TRY(hipEventRecord(s.ev[0], s.stream));
     {
         const dim3 cgrid((n + bz::kClassifyThreads * bz::kClassifyRows - 1) / (bz::kClassifyThreads * bz::kClassifyRows));
@@ -857,7 +857,7 @@ int bz_assign_device_noalloc(bz_handle h, const uint8_t *d_ext, int ext_stride, 
     if (ext_stride < 1 || ext_stride > BZ_EXT_MAX) return fail(BZ_E_LIMIT, "ext_stride %d outside 1..%d", ext_stride, BZ_EXT_MAX);
     if (n == 0) return BZ_OK;
     if (!d_ext || !d_ext_len || !d_bc_off || !d_bc_len || !d_hit || !d_ed || !d_end_idx || !d_flags) return fail(BZ_E_ARG, "null device array");
-    if ((ext_stride & 15) == 0 && ((uintptr_t)d_ext & 15) != 0) return fail(BZ_E_ARG, "d_ext must be 16-byte aligned for a stride that is a multiple of 16");
+    if ((ext_stride & 7) == 0 && ((uintptr_t)d_ext & 7) != 0) return fail(BZ_E_ARG, "d_ext must be 8-byte aligned for a stride that is a multiple of 8");
     if (((uintptr_t)d_hit & 3) != 0) return fail(BZ_E_ARG, "d_hit must be 4-byte aligned");
     unsigned char *const base = g_scratch_ptr[h->device];     // this GPU's copy of `scratch` (scratch_init, bz_create)
     if (!base) return fail(BZ_E_STATE, "no scratch address for device %d", h->device);

@@ -43,31 +43,27 @@ constexpr unsigned kFlagExact = 1u, kFlagBlank = 2u, kFlagAmbig = 4u, kFlagGener
 __device__ __forceinline__ uint32_t base_code(uint32_t c) { return (c >> 1) & 3u; }   // A0 C1 T2 G3
 __device__ __forceinline__ bool is_acgt(uint32_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
 
-// First 20 bytes of a row as five little-endian words.  Rows of the packed layout (stride a multiple
-// of 16, >= 32, base 16-B aligned) take two 16-byte loads; anything else is read byte by byte.
+// First 20 bytes of a row as five little-endian words.  Rows of the packed layout (stride a multiple of 8, >= 24, base
+// 8-byte aligned: 24 is the tightest stride that holds a 20-nt extension, 32 what the file pipeline uses for barcodes of
+// up to 28 nt) take three naturally aligned 8-byte loads; anything else is read byte by byte.
 struct RowBytes {
     uint32_t w[8];
     __device__ __forceinline__ uint32_t at(int j) const { return (w[j >> 2] >> (8 * (j & 3))) & 0xFFu; }
 };
-__device__ __forceinline__ RowBytes load_row_packed(const uint8_t *row) {      // packed layout only (host checks the stride)
+__host__ __device__ constexpr bool packed_stride(int stride) { return (stride & 7) == 0 && stride >= 24; }
+__device__ __forceinline__ RowBytes load_row_packed(const uint8_t *row) {      // packed layout only (host checks stride and alignment)
     RowBytes b;
-    const uint4 lo = *(const uint4 *)row, hi = *(const uint4 *)(row + 16);
-    b.w[0] = lo.x; b.w[1] = lo.y; b.w[2] = lo.z; b.w[3] = lo.w;
-    b.w[4] = hi.x; b.w[5] = hi.y; b.w[6] = hi.z; b.w[7] = hi.w;
+    const uint2 a = *(const uint2 *)row, c = *(const uint2 *)(row + 8), d = *(const uint2 *)(row + 16);
+    b.w[0] = a.x; b.w[1] = a.y; b.w[2] = c.x; b.w[3] = c.y; b.w[4] = d.x; b.w[5] = d.y; b.w[6] = 0; b.w[7] = 0;
     return b;
 }
 __device__ __forceinline__ RowBytes load_row(const uint8_t *row, int stride) {
+    if (packed_stride(stride)) return load_row_packed(row);   // wave-uniform
     RowBytes b;
-    if ((stride & 15) == 0 && stride >= 32) {                 // wave-uniform
-        const uint4 lo = *(const uint4 *)row, hi = *(const uint4 *)(row + 16);
-        b.w[0] = lo.x; b.w[1] = lo.y; b.w[2] = lo.z; b.w[3] = lo.w;
-        b.w[4] = hi.x; b.w[5] = hi.y; b.w[6] = hi.z; b.w[7] = hi.w;
-    } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) b.w[k] = 0;
-        const int nb = stride < kTextCols ? stride : kTextCols;
-        for (int j = 0; j < nb; ++j) b.w[j >> 2] |= (uint32_t)row[j] << (8 * (j & 3));
-    }
+    for (int k = 0; k < 8; ++k) b.w[k] = 0;
+    const int nb = stride < kTextCols ? stride : kTextCols;
+    for (int j = 0; j < nb; ++j) b.w[j >> 2] |= (uint32_t)row[j] << (8 * (j & 3));
     return b;
 }
 

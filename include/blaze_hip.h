@@ -104,6 +104,8 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
 /* Rows.  Row r is the extension ext[r*ext_stride .. +ext_len[r]) =
  * pre_bc_flanking[-2:] + putative_bc + putative_umi[:2] (read_assignment.py:70), with
  * putative_bc at [bc_off[r], bc_off[r]+bc_len[r]).  bc_len 0 = blank row.
+ * Fastest row layout: ext_stride a multiple of 8 and >= 24 (24 holds the reference's 20-nt extension; rows are then read
+ * with aligned 8-byte loads and take the packed kernels); any other stride works and is read byte by byte.
  * Outputs per row: hit = whitelist index or -1 ('' in the reference: none, ambiguous or
  * blank); ed = final best_ed (0 for the shortcut); end_idx = bc_hit_end_idx of :76,80
  * (umi_adj = end_idx - (ext_len-1-2), :93); flags = BZ_F_*.
@@ -154,8 +156,8 @@ int bz_slot_timing(bz_handle h, int slot, float ms[8], int64_t counts[8]);
  * the set-up step and does allocate).  Results equal bz_assign_submit/wait's on the same rows (the max_ed 2 scan
  * verifies straight out of the seed buckets instead of writing candidate lists); rows whose lengths do not fit are
  * returned as BZ_F_BLANK | BZ_F_INVALID with hit -1 instead of an error (the host cannot see them).  The
- * per-barcode histogram (bz_counts_get) is updated as by bz_assign_run.  d_ext must be 16-byte aligned when
- * ext_stride is a multiple of 16. */
+ * per-barcode histogram (bz_counts_get) is updated as by bz_assign_run.  d_ext must be 8-byte aligned when
+ * ext_stride is a multiple of 8. */
 #define BZ_NOALLOC_MAX_ROWS 262144
 int bz_assign_device_noalloc(bz_handle h, const uint8_t *d_ext, int ext_stride, const uint8_t *d_ext_len,
                              const uint8_t *d_bc_off, const uint8_t *d_bc_len, int64_t n, int max_ed, int32_t *d_hit,

@@ -90,6 +90,19 @@ def test_generic_equals_bitparallel(engine):
     assert np.array_equal(a[3] & FLAG_MASK, b[3] & FLAG_MASK)
 
 
+@pytest.mark.parametrize("stride", [20, 21, 24, 32, 40, 64])
+def test_row_strides(engine, oracle, stride):
+    """Row layouts: multiples of 8 from 24 up take the packed kernels (aligned 8-byte loads), everything else the
+    byte-wise loaders; same results, bytes behind a row's text ignored."""
+    rows, wl = _synthetic(5000, 700, err=3.0, seed=23)
+    ext, el, bo, bl = synth.pack_ext(rows, stride=stride)
+    if stride > 20:
+        ext[:, 20:] = np.frombuffer(b"ACGTN\0", dtype=np.uint8)[np.random.default_rng(3).integers(0, 6, size=(ext.shape[0], stride - 20))]
+    _compare(engine, oracle, ext, el, bo, bl, [w.tobytes() for w in wl], 2)
+    t = engine.timing(0)
+    assert t["rows_generic"] == 0 and t["rows_bitparallel"] > 1000
+
+
 def test_irregular_rows(engine, oracle):
     """Short flanks / short UMI (ext 16..19), N and lower case, short and long putative_bc."""
     rows, wl = _synthetic(3000, 200, err=2.0, seed=13)

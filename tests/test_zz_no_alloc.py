@@ -144,7 +144,7 @@ def test_noalloc_limits_and_invalid_rows(engine):
     stride = ext.shape[1]
     bufs = [DevBuf(n * stride), DevBuf(n), DevBuf(n), DevBuf(n), DevBuf(4 * n), DevBuf(n), DevBuf(n), DevBuf(n)]
     try:
-        for width in (stride, 24):                   # 32: the packed row layout; 24: the general kernels
+        for width in (stride, 24, 20):               # 32, 24: the packed row layouts; 20: the general kernels
             e = np.ascontiguousarray(ext[:, :width])
             got = run_noalloc(engine, bufs, e, el2, bo2, bl2, 2)
             ref = engine.assign(e, el, bo, bl, 2)

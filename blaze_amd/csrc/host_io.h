@@ -30,9 +30,11 @@
 #include <array>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <deque>
 #include <exception>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -189,6 +191,30 @@ class GzLines : public LineSource {
     bool eof_ = false;
 };
 
+// a whole decompressed file in memory: lines are NOT copied (as with a mapping); the buffer lives as long as the source
+// object, which every chunk that holds lines of it keeps alive
+class MemLines : public LineSource {
+   public:
+    MemLines(std::unique_ptr<char[]> &&buf, size_t size, std::function<void()> on_free)
+        : buf_(std::move(buf)), size_(size), on_free_(std::move(on_free)) {}
+    ~MemLines() override { buf_.reset(); if (on_free_) on_free_(); }
+    bool next(Arena &, Span &out) override {
+        if (pos_ >= size_) return false;
+        char *p = buf_.get() + pos_;
+        char *nl = (char *)memchr(p, '\n', size_ - pos_);
+        size_t len = nl ? (size_t)(nl - p) : size_ - pos_;
+        pos_ += len + (nl ? 1 : 0);
+        if (len && p[len - 1] == '\r') --len;
+        if (len > 0xFFFFFFFFu) throw std::runtime_error("line longer than 4 GiB");
+        out.p = p; out.len = (uint32_t)len;
+        return true;
+    }
+   private:
+    std::unique_ptr<char[]> buf_;
+    size_t size_ = 0, pos_ = 0;
+    std::function<void()> on_free_;
+};
+
 inline bool ends_with_gz(const std::string &p) { return p.size() >= 3 && p.compare(p.size() - 3, 3, ".gz") == 0; }
 inline std::shared_ptr<LineSource> open_lines(const std::string &path) {      // '.gz' decides, as read_assignment.py:151
     if (ends_with_gz(path)) return std::make_shared<GzLines>(path);
@@ -196,6 +222,138 @@ inline std::shared_ptr<LineSource> open_lines(const std::string &path) {      //
     if (stat(path.c_str(), &st) == 0 && !S_ISREG(st.st_mode)) return std::make_shared<GzLines>(path);   // pipes etc.: streamed
     return std::make_shared<MmapLines>(path);
 }
+
+// ---- the job's FASTQ files, opened in order; gzipped ones are inflated AHEAD of the reader by a pool of threads --------
+// A nanopore run is thousands of `.fastq.gz` files of a few thousand reads each (the reference opens them one after
+// another with gzip.open, read_assignment.py:151-153, main.py:311-315).  zlib inflates ~0.3-0.5 GB/s per thread, a
+// twentieth of what the reader's line scan does on a mapping, so with one reader thread gzipped input ran at a twentieth
+// of the plain rate.  Whole files are independent: `threads` workers inflate the next files into memory while the reader
+// consumes the current one; files are handed out strictly in order; at most `budget` bytes of inflated text (counted
+// from when a file is complete until the last chunk holding its lines is written) and `threads + 2` files are ahead.
+// A gzipped file larger than kStreamAbove compressed bytes is streamed by the reader itself (GzLines) as before: it
+// may not fit in memory.  BLAZE_AMD_GZ_PREFETCH=0 turns the pool off.
+class FastqFiles {
+   public:
+    static constexpr int64_t kStreamAbove = (int64_t)512 << 20;
+    FastqFiles(const std::vector<std::string> &paths, int threads) : paths_(paths), slots_(paths.size()) {
+        const char *e = getenv("BLAZE_AMD_GZ_PREFETCH");
+        const bool enabled = !(e && e[0] == '0');
+        for (size_t k = 0; k < paths_.size(); ++k) {
+            struct stat st;
+            slots_[k].prefetch = enabled && ends_with_gz(paths_[k]) && stat(paths_[k].c_str(), &st) == 0 && S_ISREG(st.st_mode) &&
+                                 (int64_t)st.st_size <= kStreamAbove;
+            n_prefetch_ += slots_[k].prefetch;
+        }
+        if (const char *b = getenv("BLAZE_AMD_GZ_PREFETCH_MB")) budget_ = std::max<int64_t>(1, atoll(b)) << 20;
+        const int nt = n_prefetch_ ? std::max(1, std::min<int>(threads, (int)n_prefetch_)) : 0;
+        ahead_ = (size_t)nt + 2;
+        for (int t = 0; t < nt; ++t) workers_.emplace_back([this] { work(); });
+    }
+    ~FastqFiles() {
+        { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    size_t size() const { return paths_.size(); }
+    // the k-th file's lines; k must go up by one per call
+    std::shared_ptr<LineSource> open(size_t k) {
+        Slot &sl = slots_[k];
+        if (!sl.prefetch) {
+            { std::lock_guard<std::mutex> g(mu_); next_needed_ = k + 1; }
+            cv_.notify_all();
+            return open_lines(paths_[k]);
+        }
+        std::unique_lock<std::mutex> lk(mu_);
+        next_needed_ = k;
+        cv_.notify_all();
+        cv_.wait(lk, [&] { return sl.done; });
+        next_needed_ = k + 1;
+        cv_.notify_all();
+        if (sl.err) std::rethrow_exception(sl.err);
+        const int64_t n = (int64_t)sl.size;
+        auto state = state_;
+        return std::make_shared<MemLines>(std::move(sl.buf), sl.size, [state, n] {
+            { std::lock_guard<std::mutex> g(state->mu); state->bytes -= n; }
+            state->cv.notify_all();
+        });
+    }
+
+   private:
+    struct Slot { bool prefetch = false, started = false, done = false; std::unique_ptr<char[]> buf; size_t size = 0; std::exception_ptr err; };
+    struct Shared { std::mutex mu; std::condition_variable cv; int64_t bytes = 0; };     // outlives this object: chunks free buffers later
+    void work() {
+        for (;;) {
+            size_t k;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                for (;;) {
+                    if (stop_) return;
+                    k = scan_;
+                    while (k < slots_.size() && (!slots_[k].prefetch || slots_[k].started)) ++k;
+                    if (k >= slots_.size()) return;
+                    // the file the reader is waiting for is always taken; others only inside the window and the budget
+                    bool room;
+                    { std::lock_guard<std::mutex> g(state_->mu); room = state_->bytes < budget_; }
+                    if (k <= next_needed_ || (k < next_needed_ + ahead_ && room)) break;
+                    cv_.wait_for(lk, std::chrono::milliseconds(20));
+                }
+                slots_[k].started = true;
+                scan_ = k + 1;
+            }
+            std::unique_ptr<char[]> buf;
+            size_t size = 0;
+            std::exception_ptr err;
+            try {
+                size = inflate_file(paths_[k], buf);
+            } catch (...) {
+                err = std::current_exception();
+            }
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                { std::lock_guard<std::mutex> g2(state_->mu); state_->bytes += (int64_t)size; }
+                slots_[k].buf = std::move(buf);
+                slots_[k].size = size;
+                slots_[k].err = err;
+                slots_[k].done = true;
+            }
+            cv_.notify_all();
+        }
+    }
+    static size_t inflate_file(const std::string &path, std::unique_ptr<char[]> &out) {
+        gzFile f = gzopen(path.c_str(), "rb");                  // multi-member files and plain text behind a .gz name included
+        if (!f) throw std::runtime_error("cannot open " + path);
+        gzbuffer(f, 1 << 20);
+        struct stat st;
+        size_t cap = (size_t)4 << 20;
+        if (stat(path.c_str(), &st) == 0) cap = std::max<size_t>(cap, (size_t)st.st_size * 4);
+        size_t n = 0;
+        std::unique_ptr<char[]> buf(new char[cap]);             // not value-initialised
+        for (;;) {
+            if (n == cap) {
+                std::unique_ptr<char[]> bigger(new char[cap * 2]);
+                memcpy(bigger.get(), buf.get(), n);
+                buf.swap(bigger);
+                cap *= 2;
+            }
+            const int got = gzread(f, buf.get() + n, (unsigned)std::min<size_t>(cap - n, (size_t)1 << 30));
+            if (got < 0) { gzclose(f); throw std::runtime_error("read error in " + path); }
+            if (got == 0) break;
+            n += (size_t)got;
+        }
+        gzclose(f);
+        out = std::move(buf);
+        return n;
+    }
+    const std::vector<std::string> &paths_;
+    std::vector<Slot> slots_;
+    std::shared_ptr<Shared> state_ = std::make_shared<Shared>();
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<std::thread> workers_;
+    size_t scan_ = 0, next_needed_ = 0, ahead_ = 2, n_prefetch_ = 0;
+    int64_t budget_ = (int64_t)2 << 30;
+    bool stop_ = false;
+};
 
 // reads in a FASTQ file as helper.fastq_parser would yield them: one per four lines (a trailing partial record counts,
 // the reader raises on it later)
@@ -335,7 +493,7 @@ void parallel_for(int n_items, int n_threads, F &&fn) {
 // ---- reader: FASTQ records + the same number of csv lines, cut into device batches of whole reference batches --
 class ChunkReader {
    public:
-    explicit ChunkReader(const Job &job) : job_(job), csv_(open_lines(job.csv)) {
+    explicit ChunkReader(const Job &job) : job_(job), csv_(open_lines(job.csv)), files_(job.fastq_fns, job.n_threads) {
         Arena tmp; Span s;
         if (!csv_->next(tmp, s)) throw std::runtime_error("putative bc csv is empty: " + job.csv);   // header (:150 `next(f)`)
         for (int64_t k = 0; k < job.csv_skip_rows; ++k) {
@@ -352,7 +510,7 @@ class ChunkReader {
         while ((int64_t)ch->reads.size() < job_.device_batch_rows) {
             if (!fq_) {
                 if (file_idx_ >= job_.fastq_fns.size()) break;
-                fq_ = open_lines(job_.fastq_fns[file_idx_++]);
+                fq_ = files_.open(file_idx_++);
                 ch->sources.push_back(fq_);
             }
             // one reference batch: up to batch_size reads of THIS file (helper.batch_iterator is per file, :156-158)
@@ -380,6 +538,7 @@ class ChunkReader {
    private:
     const Job &job_;
     std::shared_ptr<LineSource> csv_;
+    FastqFiles files_;
     std::shared_ptr<LineSource> fq_;
     size_t file_idx_ = 0;
 };
@@ -626,7 +785,7 @@ struct S1Job {
 
 class FastqChunkReader {
    public:
-    explicit FastqChunkReader(const S1Job &job) : job_(job) {}
+    explicit FastqChunkReader(const S1Job &job) : job_(job), files_(job.fastq_fns, job.n_threads) {}
     std::unique_ptr<S1Chunk> next() {
         auto ch = std::make_unique<S1Chunk>();
         if (fq_) ch->sources.push_back(fq_);
@@ -635,7 +794,7 @@ class FastqChunkReader {
         while ((int64_t)ch->reads.size() < job_.device_batch_reads && bytes < job_.device_batch_bytes) {
             if (!fq_) {
                 if (file_idx_ >= job_.fastq_fns.size()) break;
-                fq_ = open_lines(job_.fastq_fns[file_idx_++]);
+                fq_ = files_.open(file_idx_++);
                 ch->sources.push_back(fq_);
             }
             const uint32_t start = (uint32_t)ch->reads.size();
@@ -658,6 +817,7 @@ class FastqChunkReader {
     }
    private:
     const S1Job &job_;
+    FastqFiles files_;
     std::shared_ptr<LineSource> fq_;
     size_t file_idx_ = 0;
 };

@@ -358,7 +358,10 @@ def assign_read_sharded(comm, fastq_fns, fastq_out, putative_bc_csv, whitelsit_c
     spans = partition_files([os.path.getsize(f) for f in fastq_fns], comm.world)
     lo, hi = spans[comm.rank]
     mine = np.zeros(comm.world, dtype=np.int64)
-    mine[comm.rank] = sum(count_reads(f) for f in fastq_fns[lo:hi])
+    # counting gzipped files means inflating them: the files of this rank side by side (the native counter drops the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max(1, min(int(n_process or 1), 16, hi - lo or 1))) as pool:
+        mine[comm.rank] = sum(pool.map(count_reads, fastq_fns[lo:hi]))
     per_rank = comm.allreduce_sum_i64(mine)                     # every rank's read count
     skip = int(per_rank[:comm.rank].sum())
     part = part_path(fastq_out, comm.rank)

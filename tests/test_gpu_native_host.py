@@ -287,3 +287,41 @@ def test_file_shards_concatenate_to_the_single_run(tmp_path, gz):
     if not gz:
         assert open(out, "rb").read() == open(whole, "rb").read()
     assert not [f for f in os.listdir(tmp_path) if ".part" in f]
+
+
+def test_many_gzipped_inputs_prefetch_pool(tmp_path, monkeypatch):
+    """A nanopore run's shape: many small `.fastq.gz` files (some empty, one plain).  The pool that inflates the next
+    files ahead of the reader (host_io.h: FastqFiles) gives the bytes of the streaming reader and of the pandas host,
+    with a roomy and with a one-megabyte budget, for step 3 and for the stage-1 table."""
+    from blaze_amd import putative_bc
+    n = 6000
+    fns, pc, pw, bounds = _make_files(tmp_path, n, 300, seed=17, n_files=12, quirks=False)
+    gz_fns = []
+    for k, fn in enumerate(fns):
+        if k == 5 or fn.endswith(".gz"):
+            gz_fns.append(fn)
+            continue
+        raw = open(fn, "rb").read()
+        with gzip.open(fn + ".gz", "wb", compresslevel=1) as f:
+            f.write(raw)
+        gz_fns.append(fn + ".gz")
+    empty = str(tmp_path / "none.fastq.gz")
+    with gzip.open(empty, "wb") as f:
+        pass
+    gz_fns.insert(3, empty)
+    kw = dict(fastq_fns=gz_fns, putative_bc_csv=pc, whitelsit_csv=pw, max_ed=2, batchsize=250, restrand=True)
+    want = ra.assign_read(fastq_out=str(tmp_path / "pandas.fastq"), n_process=1, host="python", **kw)
+    ref = (tmp_path / "pandas.fastq").read_bytes()
+    eng = ra.get_engine(0)
+    for name, env in (("pool", {}), ("tight", {"BLAZE_AMD_GZ_PREFETCH_MB": "1"}), ("stream", {"BLAZE_AMD_GZ_PREFETCH": "0"})):
+        for k in ("BLAZE_AMD_GZ_PREFETCH_MB", "BLAZE_AMD_GZ_PREFETCH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = ra.assign_read(fastq_out=str(tmp_path / f"{name}.fastq"), n_process=8, host="native", **kw)
+        assert tuple(map(int, got)) == tuple(map(int, want)), name
+        assert (tmp_path / f"{name}.fastq").read_bytes() == ref, name
+        counts = putative_bc.putative_bc_files([eng], gz_fns, str(tmp_path / f"{name}.csv"), kit="3v3", umi_len=12, min_q=15,
+                                               batch_size=250, n_threads=8)
+        assert sum(counts.values()) == n
+    assert (tmp_path / "pool.csv").read_bytes() == (tmp_path / "stream.csv").read_bytes() == (tmp_path / "tight.csv").read_bytes()

@@ -30,9 +30,15 @@ def main():
     gz = "--gz" in sys.argv
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
         t0 = time.time()
-        fns, pc, wl, fq_bytes = write_inputs(d, n, n_cells)
+        n_files = 64 if "--gz-in" in sys.argv else 4
+        fns, pc, wl, fq_bytes = write_inputs(d, n, n_cells, n_files=n_files)
+        if "--gz-in" in sys.argv:                       # a nanopore run's shape: many .fastq.gz files of a few thousand reads
+            import subprocess
+            subprocess.check_call(["gzip", "-1"] + fns)
+            fns = [f + ".gz" for f in fns]
         gen_s = time.time() - t0
-        out = {"reads": n, "cells": n_cells, "threads": threads, "gz": gz, "fastq_bytes": fq_bytes, "generate_s": gen_s}
+        out = {"reads": n, "cells": n_cells, "threads": threads, "gz": gz, "gz_in": "--gz-in" in sys.argv, "n_files": n_files, "fastq_bytes": fq_bytes, "generate_s": gen_s,
+               "gz_prefetch": os.environ.get("BLAZE_AMD_GZ_PREFETCH", "1")}
         suffix = ".fastq.gz" if gz else ".fastq"
         kw = dict(fastq_fns=fns, putative_bc_csv=pc, whitelsit_csv=wl, max_ed=2, batchsize=1000, restrand=True)
         ra.assign_read(fastq_out=os.path.join(d, "warm" + suffix), n_process=threads, host="native", **kw)   # page cache + engine warm

@@ -155,3 +155,38 @@ def test_configs4_files_200k_reads_native_equals_pandas(tmp_path, restrand):
         got = ra.assign_read(fastq_out=str(tmp_path / "native.fastq.gz"), n_process=16, host="native", **kw)
         assert tuple(got) == tuple(exp)
         assert gzip.decompress(open(tmp_path / "native.fastq.gz", "rb").read()) == want
+
+
+def _run_k(engine, ext, el, bo, bl, max_ed, mode):
+    engine.set_option(_lib.BZ_OPT_SCAN_MODE, mode)
+    try:
+        return engine.assign(ext, el, bo, bl, max_ed)
+    finally:
+        engine.set_option(_lib.BZ_OPT_SCAN_MODE, 0)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("max_ed", [0, 1, 3])
+def test_configs1_other_max_edit_distances(engine, oracle, max_ed):
+    """--max-edit-distance is a user flag (parser.py:100): configs[1]'s 1M rows x 5,000 cells at 0, 1 and 3 -- the seeded
+    product scans (8|8-nt pieces; four 4-nt pieces at 3) against the all-pairs scan on every row and the oracle on a
+    strided sample, and the high-error setting of SURVEY 8d (sub 3 %, ins 1 %, del 2 %) so that distance 3 is populated."""
+    from concurrent.futures import ThreadPoolExecutor
+    n_rows, n_cells, chunk = 1_000_000, 5_000, 250_000
+    full = synth.full_whitelist_codes(400_000, seed=1)
+    cells = synth.cell_whitelist_codes(n_cells, full, seed=2)
+    with ThreadPoolExecutor(8) as pool:
+        parts = list(pool.map(lambda k: synth.pack_ext(synth.make_rows(chunk, cells, full, sub=0.03, ins=0.01, dele=0.02, seed=40 + k)),
+                              range(n_rows // chunk)))
+    ext, el, bo, bl = (np.concatenate([p[i] for p in parts]) for i in range(4))
+    wl = synth.codes_to_bytes(cells)
+    engine.set_whitelist_codes16(wl)
+    ref = _run_k(engine, ext, el, bo, bl, max_ed, 0)
+    assert engine.timing(0)["rows_generic"] == 0
+    _agree(ref, _run_k(engine, ext, el, bo, bl, max_ed, 1), f"all pairs, max_ed {max_ed}")
+    if max_ed:
+        assert (ref[1][ref[0] >= 0] == max_ed).sum() > 1000                      # assignments at the cut-off itself
+    idx = np.arange(0, n_rows, n_rows // 8000)[:8000]
+    o = oracle.match_rows(ext[idx], el[idx], bo[idx], bl[idx], [w.tobytes() for w in wl], max_ed, threads=16)
+    assert np.array_equal(ref[0][idx], o[0]) and np.array_equal(ref[1][idx], o[1]) and np.array_equal(ref[2][idx], o[2])
+    assert np.array_equal(ref[3][idx] & FLAG_MASK, o[3])

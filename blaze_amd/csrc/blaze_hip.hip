@@ -336,18 +336,16 @@ void launch_scan_filtered(bz_handle h, Slot &s) {
                        (int)h->n_fast, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
 }
 
-// seeded scan over fast_list; rows it could not fold (more than kMaxEvents near matches) go to
-// redo_list and are finished by the order-preserving filtered scan right behind it
+// seeded scan over fast_list (single-piece seeds); every row is finished here: the lane keeps the two smallest events per
+// distance class, which is all the fold consumes, so nothing is handed to the ordered scan any more
 template <int K>
 void launch_scan_seeded(bz_handle h, Slot &s) {
     const int block = 256;
     const int grid = (int)((s.n + block - 1) / block);
     const int plan = K == 2 ? 0 : K == 3 ? 2 : 1;
     hipLaunchKernelGGL(bz::k_scan_seeded<K>, dim3(grid), dim3(block), 0, s.stream, h->d_seed_tab[plan], h->d_seed_members[plan],
-                       h->d_planes32, (int)h->n_fast, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule, s.d_redo,
-                       s.d_counters + 2, s.d_hit, s.d_ed, s.d_end, s.d_flags);
-    hipLaunchKernelGGL(bz::k_scan_filtered<K>, dim3(grid), dim3(block), 0, s.stream, (const uint4 *)h->d_grams, h->d_planes32, h->n_blk,
-                       (int)h->n_fast, s.d_ext, s.stride, s.d_len, s.d_redo, s.d_counters + 2, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+                       h->d_planes32, (int)h->n_fast, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule,
+                       s.d_hit, s.d_ed, s.d_end, s.d_flags);
 }
 
 // pair-seeded scan, two-kernel form (whitelists whose candidate lists fit `pair_cap` slots per row)

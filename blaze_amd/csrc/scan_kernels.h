@@ -477,7 +477,6 @@ __global__ __launch_bounds__(256) void k_scan_seeded(
     const int32_t *__restrict__ tab, const int32_t *__restrict__ members, const uint32_t *__restrict__ planes32, int n_wl,
     const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
     const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int tie,
-    int32_t *__restrict__ redo_list, int32_t *__restrict__ n_redo,
     int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
     using Plan = SeedPlan<K>;
     __shared__ uint32_t fifo[kQCap][256];

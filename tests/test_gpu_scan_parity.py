@@ -299,7 +299,7 @@ def test_low_complexity_whitelist_fills_the_candidate_fifo(engine, oracle):
                 _compare(engine, oracle, ext, el, bo, bl, wl, max_ed, shortcut=shortcut, scan_mode=mode)
                 if mode in (0, 3, FUSED):
                     redo += engine.timing(0)["rows_redo"]
-    assert redo > 0, "expected rows with more than 8 near matches (seeded scan hands them to the filtered scan)"
+    assert redo > 0, "expected rows whose candidate lists overflow (the pair-seeded scan hands them to the ordered filtered scan)"
 
 
 def test_seeded_filtered_bruteforce_agree_large(engine):

@@ -137,6 +137,8 @@ struct bz_engine {
     int32_t *d_reg_to_orig = nullptr;   //   sub-list index -> index in the caller's list
     uint8_t *d_irr_bytes = nullptr;     //   the irregular entries, back to back
     int64_t *d_irr_off = nullptr;
+    uint4 *d_irr_peq = nullptr;         //   per irregular entry: which positions hold A / C / T / G (code order), bit i = character i
+    int2 *d_irr_meta = nullptr;         //   {length, index in the caller's list}
     int n_pairs = 0;
     uint2 *d_planes = nullptr;
     uint4 *d_grams = nullptr;          // 3-gram sets, two barcodes per uint4, padded to 32 barcodes
@@ -210,8 +212,8 @@ void free_whitelist(bz_handle h) {
     hipFree(h->d_pair_bitmap); hipFree(h->d_pair_tab); hipFree(h->d_pair_members); hipFree(h->d_pair_tab8);
     h->d_pair_bitmap = nullptr; h->d_pair_tab = nullptr; h->d_pair_members = nullptr; h->d_pair_tab8 = nullptr;
     h->pair_cap = 0;
-    hipFree(h->d_reg_to_orig); hipFree(h->d_irr_bytes); hipFree(h->d_irr_off);
-    h->d_reg_to_orig = nullptr; h->d_irr_bytes = nullptr; h->d_irr_off = nullptr;
+    hipFree(h->d_reg_to_orig); hipFree(h->d_irr_bytes); hipFree(h->d_irr_off); hipFree(h->d_irr_peq); hipFree(h->d_irr_meta);
+    h->d_reg_to_orig = nullptr; h->d_irr_bytes = nullptr; h->d_irr_off = nullptr; h->d_irr_peq = nullptr; h->d_irr_meta = nullptr;
     h->mixed = 0; h->n_irr = 0; h->n_fast = 0;
     h->d_planes = nullptr; h->d_sorted_codes = nullptr; h->d_sorted_idx = nullptr;
     h->d_wl_bytes = nullptr; h->d_wl_off = nullptr; h->d_counts = nullptr;
@@ -399,6 +401,18 @@ void launch_pair_stream(bz_handle h, Slot &s) {
                        (int)h->n_fast, s.d_ext, s.stride, s.d_len, s.d_redo, s.d_counters + 2, h->tie_rule, s.d_hit, s.d_ed, s.d_end, s.d_flags);
 }
 
+// mixed whitelists: remap + probe of the irregular entries, then the listed rows against the whole list (scan_kernels.h)
+template <int K>
+void launch_mixed(bz_handle h, Slot &s) {
+    const int n = (int)s.n;
+    hipLaunchKernelGGL(bz::k_mixed_fix<K>, dim3(std::min((n + 255) / 256, 8 * h->n_cu)), dim3(256), 0, s.stream, h->d_reg_to_orig, h->d_irr_peq,
+                       h->d_irr_meta, h->d_irr_bytes, h->d_irr_off, h->n_irr, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, n, h->tie_rule,
+                       s.d_redo, s.d_counters + 3, s.d_hit, s.d_flags);
+    hipLaunchKernelGGL(bz::k_fix_rows<K>, dim3(2 * h->n_cu), dim3(256), 0, s.stream, h->d_reg_to_orig, h->d_planes32, (int)h->n_fast, h->d_irr_peq,
+                       h->d_irr_meta, h->d_irr_bytes, h->d_irr_off, h->n_irr, s.d_ext, s.stride, s.d_len, s.d_redo, s.d_counters + 3, h->tie_rule,
+                       s.d_hit, s.d_ed, s.d_end, s.d_flags);
+}
+
 // the striped totals behind counts[n_wl+2] -> counts[n_wl], counts[n_wl+1]
 int fold_totals(bz_handle h, hipStream_t st) {
     hipLaunchKernelGGL(bz::k_fold_totals, dim3(1), dim3(64), 0, st, h->d_counts, (int)h->n_wl);
@@ -447,15 +461,15 @@ int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed
         }
         HIP_TRY(hipGetLastError());
     }
-    if (h->mixed) {
+    if (h->mixed && max_ed <= bz::kMaxK) {
         // indices of the regular sub-list -> caller's indices; scored rows within max_ed of an irregular entry -> fix list
-        // (the hand-over list's buffer: its rows have been consumed by now; counter 3)
-        hipLaunchKernelGGL(bz::k_mixed_fix, dim3(std::min((n + 255) / 256, 8 * h->n_cu)), dim3(256), 0, s.stream, h->d_reg_to_orig, h->d_irr_bytes,
-                           h->d_irr_off, h->n_irr, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, n, max_ed, h->tie_rule, s.d_redo,
-                           s.d_counters + 3, s.d_hit, s.d_flags);
-        hipLaunchKernelGGL(bz::k_scan_generic, dim3(std::min((n + 63) / 64, 16 * h->n_cu)), dim3(64), 0, s.stream, h->d_wl_bytes, h->d_wl_off, (int)h->n_wl,
-                           s.d_ext, s.stride, s.d_len, s.d_off, s.d_bcl, s.d_redo, s.d_counters + 3, max_ed, h->tie_rule,
-                           h->shortcut, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+        // (the hand-over list's buffer: its rows have been consumed by now; counter 3), re-scored against the whole list
+        switch (max_ed) {
+            case 0: launch_mixed<0>(h, s); break;
+            case 1: launch_mixed<1>(h, s); break;
+            case 2: launch_mixed<2>(h, s); break;
+            default: launch_mixed<3>(h, s); break;
+        }
         HIP_TRY(hipGetLastError());
     }
     if (prof) HIP_TRY(hipEventRecord(s.ev[2], s.stream));
@@ -586,7 +600,9 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
     // more than kMaxIrregular send every row through the byte-wise scan
     constexpr int64_t kMaxIrregular = 256;
     std::vector<int32_t> reg_pos, irr_pos;
+    bool empty_entry = false;
     for (int64_t k = 0; k < n; ++k) {
+        empty_entry = empty_entry || offsets[k + 1] == offsets[k];
         bool ok = offsets[k + 1] - offsets[k] == bz::kBcLen;
         const char *w = bytes + offsets[k];
         for (int i = 0; ok && i < bz::kBcLen; ++i) ok = w[i] == 'A' || w[i] == 'C' || w[i] == 'G' || w[i] == 'T';
@@ -594,7 +610,9 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
         else if ((int64_t)irr_pos.size() <= kMaxIrregular) irr_pos.push_back((int32_t)k);
     }
     const int64_t nf = (int64_t)reg_pos.size();
-    const bool regular = nf > 0 && n - nf <= kMaxIrregular;
+    // (an empty entry is a falsy hit in the reference's fold and event words hold the index in 25 bits: such lists take
+    // the byte-wise scan as a whole when they are not all regular)
+    const bool regular = nf > 0 && (nf == n || (n - nf <= kMaxIrregular && !empty_entry && n < ((int64_t)1 << 25)));
     const bool mixed = regular && nf < n;
     // byte form (generic kernel + histogram size)
     std::vector<int64_t> off(n + 1);
@@ -778,10 +796,24 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
         if (mixed) {
             std::vector<char> ib;
             std::vector<int64_t> io(1, 0);
+            std::vector<uint4> peq;
+            std::vector<int2> meta;
             for (int32_t k : irr_pos) {
                 ib.insert(ib.end(), bytes + offsets[k], bytes + offsets[k + 1]);
                 io.push_back((int64_t)ib.size());
+                const int m = (int)(offsets[k + 1] - offsets[k]);
+                uint32_t q[4] = {0, 0, 0, 0};                       // code order A C T G ((ascii >> 1) & 3)
+                for (int i = 0; i < std::min(m, 32); ++i) {
+                    const char c = bytes[offsets[k] + i];
+                    if (c == 'A' || c == 'C' || c == 'G' || c == 'T') q[((unsigned char)c >> 1) & 3u] |= 1u << i;
+                }
+                peq.push_back(make_uint4(q[0], q[1], q[2], q[3]));
+                meta.push_back(make_int2(m, k));
             }
+            HIP_TRY(hipMalloc(&h->d_irr_peq, peq.size() * sizeof(uint4)));
+            HIP_TRY(hipMalloc(&h->d_irr_meta, meta.size() * sizeof(int2)));
+            HIP_TRY(hipMemcpy(h->d_irr_peq, peq.data(), peq.size() * sizeof(uint4), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(h->d_irr_meta, meta.data(), meta.size() * sizeof(int2), hipMemcpyHostToDevice));
             HIP_TRY(hipMalloc(&h->d_reg_to_orig, nf * sizeof(int32_t)));
             HIP_TRY(hipMalloc(&h->d_irr_bytes, std::max<size_t>(ib.size(), 1)));
             HIP_TRY(hipMalloc(&h->d_irr_off, io.size() * sizeof(int64_t)));

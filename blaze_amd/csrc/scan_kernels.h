@@ -1365,18 +1365,62 @@ __global__ __launch_bounds__(256) void k_pair_tail(
 
 // Mixed whitelists: a list with a FEW entries outside the packed shape (not 16 nt, or not all ACGT) keeps the fast path.
 // The seed indices, planes and the shortcut table are built over the regular entries only (the sub-list keeps their
-// relative order), so every result of the fast kernels is an index into the sub-list.  This kernel, behind the scan,
-//   (1) maps those indices back to the caller's order (reg_to_orig), and
-//   (2) tests every scored row against the irregular entries (byte-wise DP, the same routine k_scan_generic runs): a row
-//       within max_ed of one of them is listed in fix_list and re-scored by k_scan_generic over the WHOLE list in the
-//       caller's order.  Every other row is final: the reference's fold (read_assignment.py:73-85) ignores an entry
-//       whose distance exceeds best_ed <= max_ed, so leaving the irregular entries out changes nothing for it, and the
-//       relative order of the entries that do take part is kept.  Rows that took the exact-match shortcut are final
-//       too (:61-62 returns before the fold), and a regular putative barcode can only equal a regular entry.
+// relative order), so every result of the fast kernels is an index into the sub-list.  Behind the scan,
+//   k_mixed_fix<K>  (1) maps those indices back to the caller's order (reg_to_orig), and (2) tests every scored row
+//       against the irregular entries: a row within K = max_ed of one of them is listed in fix_list.  Every other row is
+//       final: the reference's fold (read_assignment.py:73-85) ignores an entry whose distance exceeds best_ed <= max_ed,
+//       so leaving the irregular entries out changes nothing for it, and the relative order of the entries that do take
+//       part is kept.  Rows that took the exact-match shortcut are final too (:61-62 returns before the fold), and a
+//       regular putative barcode can only equal a regular entry.
+//   k_fix_rows<K>   one workgroup per listed row re-scores it against the WHOLE list: the regular entries by the exact
+//       bit-parallel pass on their planes, the irregular ones as below, lanes striding over the entries; only the two
+//       smallest events of each distance class (by index in the caller's order) can reach the fold, so the lanes keep
+//       two per class, LDS atomics pick the workgroup's two, and one lane replays the fold.
+// An irregular entry of 1..32 characters that is not longer than the text is scored bit-parallel too: the text of a
+// scored row is all ACGT, so four match masks per entry (bit i: entry[i] is that letter; any other character matches
+// nothing) drive the same K-error Shift-And; its accept bit sits at the entry's last character.  Longer entries (the text
+// then is the pattern, as in the replaced FFI) take the byte-wise DP.  Empty entries are not admitted to this path (an
+// empty hit is falsy in the reference's fold; such a list takes the byte-wise scan as a whole).
+constexpr int kEndNone = 31;                                      // event words hold end + 0..19, or this for "no column" (end -1)
+
+template <int K>
+__device__ __forceinline__ void irr_exact(const uint4 peq, int m, const uint8_t *__restrict__ entry, const uint8_t *__restrict__ row,
+                                          uint64_t tc, int len, int tie, int &ed, int &end) {
+    if (m >= 1 && m <= 32 && m <= len) {
+        ShiftAnd<K, 1u> A;
+        A.init();
+        const uint32_t acc = 1u << (m - 1);
+        int best_cnt = m <= K ? K + 1 - m : 0, best_end = -1;     // before any column: every character deleted, D[m][0] = m
+        for (int j = 0; j < len; ++j) {
+            const uint32_t code = (uint32_t)(tc >> (2 * j)) & 3u;
+            const uint32_t eq = code == 0u ? peq.x : code == 1u ? peq.y : code == 2u ? peq.z : peq.w;
+            A.step(eq);
+            int cnt = 0;
+#pragma unroll
+            for (int d = 0; d <= K; ++d) cnt += (A.R[d] & acc) != 0u;
+            if (cnt > best_cnt || (tie && cnt == best_cnt && cnt > 0)) { best_cnt = cnt; best_end = j; }
+        }
+        ed = K + 1 - best_cnt;
+        end = ed <= K ? best_end : -1;
+    } else {
+        ed = dev_sub_edit_distance(entry, m, row, len, K, tie, end);
+    }
+}
+
+// the text of a regular row: 2-bit codes (column j at bits 2j) from its bytes
+__device__ __forceinline__ uint64_t row_codes(const RowBytes &rb, int len) {
+    uint64_t tc = 0;
+#pragma unroll
+    for (int j = 0; j < kTextCols; ++j) tc |= (uint64_t)(j < len ? base_code(rb.at(j)) : 0u) << (2 * j);
+    return tc;
+}
+
+template <int K>
 __global__ __launch_bounds__(256) void k_mixed_fix(
-    const int32_t *__restrict__ reg_to_orig, const uint8_t *__restrict__ irr_bytes, const int64_t *__restrict__ irr_off, int n_irr,
+    const int32_t *__restrict__ reg_to_orig, const uint4 *__restrict__ irr_peq, const int2 *__restrict__ irr_meta,
+    const uint8_t *__restrict__ irr_bytes, const int64_t *__restrict__ irr_off, int n_irr,
     const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
-    const int32_t *__restrict__ fast_list, const int32_t *__restrict__ n_fast_ptr, int n, int max_ed, int tie,
+    const int32_t *__restrict__ fast_list, const int32_t *__restrict__ n_fast_ptr, int n, int tie,
     int32_t *__restrict__ fix_list, int32_t *__restrict__ n_fix, int32_t *__restrict__ hit, const uint8_t *__restrict__ flags) {
     const int first = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
     for (int r = first; r < n; r += step) {
@@ -1388,13 +1432,102 @@ __global__ __launch_bounds__(256) void k_mixed_fix(
         const int r = fast_list[slot];
         const uint8_t *row = ext + (size_t)r * ext_stride;
         const int len = ext_len[r];
+        const uint64_t tc = row_codes(load_row(row, ext_stride), len);
         bool near = false;
         for (int k = 0; k < n_irr && !near; ++k) {
-            const int64_t o = irr_off[k];
-            int end;
-            near = dev_sub_edit_distance(irr_bytes + o, (int)(irr_off[k + 1] - o), row, len, max_ed, tie, end) <= max_ed;
+            int ed, end;
+            irr_exact<K>(irr_peq[k], irr_meta[k].x, irr_bytes + irr_off[k], row, tc, len, tie, ed, end);
+            near = ed <= K;
         }
         if (near) fix_list[atomicAdd(n_fix, 1)] = r;
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_fix_rows(
+    const int32_t *__restrict__ reg_to_orig, const uint32_t *__restrict__ planes32, int n_fast,
+    const uint4 *__restrict__ irr_peq, const int2 *__restrict__ irr_meta, const uint8_t *__restrict__ irr_bytes,
+    const int64_t *__restrict__ irr_off, int n_irr,
+    const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
+    const int32_t *__restrict__ fix_list, const int32_t *__restrict__ n_fix_ptr, int tie,
+    int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
+    __shared__ uint32_t s_min[2][K + 1];
+    const int n_fix = *n_fix_ptr;
+    const int tid = threadIdx.x;
+    for (int f = blockIdx.x; f < n_fix; f += gridDim.x) {         // workgroup-uniform
+        const int r = fix_list[f];
+        const uint8_t *row = ext + (size_t)r * ext_stride;
+        const int len = ext_len[r];
+        const RowBytes rb = load_row(row, ext_stride);
+        uint32_t XH[kTextCols], XL[kTextCols];
+#pragma unroll
+        for (int j = 0; j < kTextCols; ++j) {
+            const uint32_t code = base_code(j < len ? rb.at(j) : (uint32_t)'A');
+            XH[j] = (code & 2u) ? 0u : 0xFFFFFFFFu;
+            XL[j] = (code & 1u) ? 0u : 0xFFFFFFFFu;
+        }
+        const uint64_t tc = row_codes(rb, len);
+        uint32_t keep[K + 1][2];
+#pragma unroll
+        for (int c = 0; c <= K; ++c) { keep[c][0] = 0xFFFFFFFFu; keep[c][1] = 0xFFFFFFFFu; }
+        auto note = [&](int idx, int ed, int end) {
+            const uint32_t ev = ((uint32_t)idx << 7) | ((uint32_t)ed << 5) | (uint32_t)(end < 0 ? kEndNone : end);
+#pragma unroll
+            for (int c = 0; c <= K; ++c) {
+                if (c != ed) continue;
+                if (ev < keep[c][0]) { keep[c][1] = keep[c][0]; keep[c][0] = ev; }
+                else if (ev < keep[c][1]) keep[c][1] = ev;
+            }
+        };
+        for (int sub = tid; sub < n_fast; sub += 256) {
+            const uint32_t p = planes32[sub];
+            int ed, end;
+            exact_pair<K>(p & 0xFFFFu, p >> 16, XH, XL, len, tie, ed, end);
+            if (ed <= K) note(reg_to_orig[sub], ed, end);
+        }
+        for (int k = tid; k < n_irr; k += 256) {
+            int ed, end;
+            irr_exact<K>(irr_peq[k], irr_meta[k].x, irr_bytes + irr_off[k], row, tc, len, tie, ed, end);
+            if (ed <= K) note(irr_meta[k].y, ed, end);
+        }
+        if (tid <= K) { s_min[0][tid] = 0xFFFFFFFFu; s_min[1][tid] = 0xFFFFFFFFu; }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c <= K; ++c) if (keep[c][0] != 0xFFFFFFFFu) atomicMin(&s_min[0][c], keep[c][0]);
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c <= K; ++c) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                if (keep[c][t] != 0xFFFFFFFFu && keep[c][t] != s_min[0][c]) atomicMin(&s_min[1][c], keep[c][t]);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t ev[2 * (K + 1)];
+            int nev = 0;
+#pragma unroll
+            for (int c = 0; c <= K; ++c) {
+                if (s_min[0][c] != 0xFFFFFFFFu) ev[nev++] = s_min[0][c];
+                if (s_min[1][c] != 0xFFFFFFFFu) ev[nev++] = s_min[1][c];
+            }
+            for (int a = 1; a < nev; ++a) {                       // whitelist order = order of the words (index in the top bits)
+                const uint32_t v = ev[a];
+                int b = a - 1;
+                while (b >= 0 && ev[b] > v) { ev[b + 1] = ev[b]; --b; }
+                ev[b + 1] = v;
+            }
+            int best = K, hit = kHitNone, hit_end = -1;
+            bool done = false;
+            for (int a = 0; a < nev; ++a) {
+                const int e = (int)(ev[a] & 31u);
+                fold_update((int)((ev[a] >> 5) & 3u), e == kEndNone ? -1 : e, (int)(ev[a] >> 7), best, hit, hit_end, done);
+            }
+            hit_out[r] = hit >= 0 ? hit : -1;
+            ed_out[r] = (int8_t)best;
+            end_out[r] = (int8_t)(hit >= 0 ? hit_end : -1);
+            flags_out[r] = (uint8_t)(hit == kHitAmbiguous ? kFlagAmbig : 0u);
+        }
+        __syncthreads();                                          // s_min is reused by the workgroup's next row
     }
 }
 

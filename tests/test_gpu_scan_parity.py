@@ -221,6 +221,35 @@ def test_mixed_whitelist_keeps_the_fast_path(engine, oracle, max_ed, scan_mode):
     assert np.array_equal(counts[:len(wl_list)], np.bincount(hit[hit >= 0], minlength=len(wl_list)))   # caller's indices
 
 
+@pytest.mark.parametrize("tie", [0, 1])
+@pytest.mark.parametrize("max_ed", [0, 1, 2, 3])
+def test_mixed_whitelist_odd_entries(engine, oracle, max_ed, tie):
+    """Irregular entries of every kind the mixed path scores differently: shorter than max_ed (within reach of EVERY text:
+    every scored row is re-scored by k_fix_rows), 1-, 3-, 17-, 20-, 32-character entries (bit-parallel), 21- and 40-character
+    ones (longer than the text: the text becomes the pattern, byte-wise), lower case and N inside; texts of 16..20 columns."""
+    rows, wl = _synthetic(2500, 300, err=3.0, seed=81)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    for r in range(ext.shape[0]):
+        if bl[r] and r % 4 == 1:
+            ext[r, :19] = ext[r, 1:20]; el[r] = 19; bo[r] = 1
+        elif bl[r] and r % 4 == 2:
+            ext[r, :16] = ext[r, 2:18]; el[r] = 16; bo[r] = 0
+    ext[np.arange(ext.shape[1])[None, :] >= el[:, None]] = 0
+    wl_list = [w.tobytes() for w in wl]
+    a, b, c = wl_list[10], wl_list[100], wl_list[200]
+    odd = [b"A", b"ACG", a + b"T", b"GG" + b + b"CA", (c + a)[:32], c + b"ACGTA", a + b + c[:8], a.lower(), b[:5] + b"N" + b[6:], c[:15] + b"a"]
+    if max_ed >= 2:
+        odd.append(b"TC")
+    rng = np.random.default_rng(4)
+    for k, w in enumerate(odd):
+        wl_list.insert(int(rng.integers(0, len(wl_list) + 1)), w)
+    _compare(engine, oracle, ext, el, bo, bl, wl_list, max_ed, tie)
+    t = engine.timing(0)
+    assert t["rows_generic"] == 0 and t["rows_bitparallel"] > 500 and t["rows_mixed_fix"] > 0
+    if max_ed >= 1:
+        assert t["rows_mixed_fix"] == t["rows_bitparallel"]          # "A" is within one edit of any text
+
+
 def test_too_many_irregular_entries_take_the_generic_scan(engine, oracle):
     rows, wl = _synthetic(600, 400, err=2.0, seed=72)
     ext, el, bo, bl = synth.pack_ext(rows)

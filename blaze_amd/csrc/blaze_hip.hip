@@ -350,6 +350,18 @@ void launch_scan_seeded(bz_handle h, Slot &s) {
                        s.d_hit, s.d_ed, s.d_end, s.d_flags);
 }
 
+// what the workgroup-per-row scan of the irregular rows needs (scan_kernels.h: generic_row_wg)
+bz::GenericArgs generic_args(bz_handle h, const Slot &s) {
+    bz::GenericArgs a;
+    a.wl_bytes = h->d_wl_bytes; a.wl_off = h->d_wl_off; a.n_wl = (int)h->n_wl;
+    a.planes32 = h->d_planes32; a.n_fast = (int)h->n_fast; a.reg_to_orig = h->mixed ? h->d_reg_to_orig : nullptr;
+    a.irr_meta = h->d_irr_meta; a.irr_bytes = h->d_irr_bytes; a.irr_off = h->d_irr_off; a.n_irr = h->mixed ? h->n_irr : 0;
+    a.ext = s.d_ext; a.ext_stride = s.stride; a.ext_len = s.d_len; a.bc_off = s.d_off; a.bc_len = s.d_bcl;
+    a.tie = h->tie_rule; a.shortcut = h->shortcut;
+    a.hit = s.d_hit; a.ed = s.d_ed; a.end = s.d_end; a.flags = s.d_flags;
+    return a;
+}
+
 // pair-seeded scan, two-kernel form (whitelists whose candidate lists fit `pair_cap` slots per row)
 int launch_pair_two_kernels(bz_handle h, Slot &s) {
     const int stride = (int)((s.n + 63) / 64 * 64);
@@ -384,8 +396,7 @@ int launch_pair_two_kernels(bz_handle h, Slot &s) {
     // hand-over rows (ordered filtered scan) and irregular rows (byte-wise scan) in ONE launch; bz_assign_run skips its
     // own k_scan_generic launch when tail_done is set
     hipLaunchKernelGGL(bz::k_pair_tail, dim3(std::min(grid, 2 * h->n_cu)), dim3(256), 0, s.stream, (const uint4 *)h->d_grams, h->d_planes32,
-                       h->n_blk, (int)h->n_wl, h->d_wl_bytes, h->d_wl_off, s.d_ext, s.stride, s.d_len, s.d_off, s.d_bcl, s.d_redo,
-                       s.d_counters + 2, s.d_gen, s.d_counters + 1, 2, h->tie_rule, h->shortcut, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+                       h->n_blk, (int)h->n_fast, s.d_redo, s.d_counters + 2, s.d_gen, s.d_counters + 1, generic_args(h, s));
     s.tail_done = true;
     return BZ_OK;
 }
@@ -474,9 +485,22 @@ int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed
     }
     if (prof) HIP_TRY(hipEventRecord(s.ev[2], s.stream));
     if (!s.tail_done) {
-        hipLaunchKernelGGL(bz::k_scan_generic, dim3(std::min((n + 63) / 64, 16 * h->n_cu)), dim3(64), 0, s.stream, h->d_wl_bytes, h->d_wl_off, (int)h->n_wl,
-                           s.d_ext, s.stride, s.d_len, s.d_off, s.d_bcl, s.d_gen, s.d_counters + 1, max_ed, h->tie_rule,
-                           h->shortcut, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+        if (h->wl_regular && max_ed <= bz::kMaxK) {
+            // irregular rows against a list with the fast-path structures: a workgroup per row, bit-parallel per entry
+            const dim3 ggrid(std::min(n, 4 * h->n_cu));
+            const bz::GenericArgs ga = generic_args(h, s);
+            switch (max_ed) {
+                case 0: hipLaunchKernelGGL(bz::k_generic_rows<0>, ggrid, dim3(256), 0, s.stream, ga, s.d_gen, s.d_counters + 1); break;
+                case 1: hipLaunchKernelGGL(bz::k_generic_rows<1>, ggrid, dim3(256), 0, s.stream, ga, s.d_gen, s.d_counters + 1); break;
+                case 2: hipLaunchKernelGGL(bz::k_generic_rows<2>, ggrid, dim3(256), 0, s.stream, ga, s.d_gen, s.d_counters + 1); break;
+                default: hipLaunchKernelGGL(bz::k_generic_rows<3>, ggrid, dim3(256), 0, s.stream, ga, s.d_gen, s.d_counters + 1); break;
+            }
+        } else {
+            // any list, any max_ed: one lane per row, byte-wise DP over the whole list (slow; irregular lists and max_ed > 3 only)
+            hipLaunchKernelGGL(bz::k_scan_generic, dim3(std::min((n + 63) / 64, 16 * h->n_cu)), dim3(64), 0, s.stream, h->d_wl_bytes, h->d_wl_off, (int)h->n_wl,
+                               s.d_ext, s.stride, s.d_len, s.d_off, s.d_bcl, s.d_gen, s.d_counters + 1, max_ed, h->tie_rule,
+                               h->shortcut, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+        }
         HIP_TRY(hipGetLastError());
     }
     if (prof) HIP_TRY(hipEventRecord(s.ev[3], s.stream));

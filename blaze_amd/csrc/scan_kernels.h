@@ -1342,25 +1342,170 @@ __global__ void k_scan_generic(const uint8_t *__restrict__ wl_bytes, const int64
                       ext_len, bc_off, bc_len, list, max_ed, tie, shortcut, hit_out, ed_out, end_out, flags_out);
 }
 
+// ------------------------------------------------------------------------------------------
+// Irregular ROWS (N or lower case somewhere in the extension, a putative barcode that is not 16 nt, an extension longer
+// than 20) against a whitelist that has the fast-path structures (all regular, or mixed), max_ed <= 3.
+// k_scan_generic above gives such a row ONE lane that walks the whole list with the byte-wise DP: ~0.24 ms per pair with
+// the DP column in scratch memory, 1.2 s for a 5,000-entry list, and a step lasts as long as its slowest lane -- ten such
+// rows in a batch of a million made the step 12,000 times longer.  Here a WORKGROUP takes the row: its lanes stride over
+// the entries; a regular entry is scored bit-parallel in registers -- the text's per-column masks come from LDS, a
+// column that is not ACGT matches nothing (exactly what the byte compare of the reference's library does) -- with the
+// roles the replaced FFI takes: the barcode is the pattern unless the text is shorter than 16, then the text is the
+// pattern and the barcode's 16 characters the columns.  Irregular entries (mixed lists, <= 256) take the byte-wise DP,
+// one per lane.  The exact-match shortcut (`row.putative_bc in whitelist`, :61) is a byte compare over the list, smallest
+// index wins.  As everywhere, the two smallest events per distance class decide the fold: lanes keep two per class,
+// 64-bit LDS atomicMin picks the workgroup's (word = index << 16 | ed << 8 | end + 1), one lane replays the fold.
+struct GenericArgs {
+    const uint8_t *wl_bytes; const int64_t *wl_off; int n_wl;            // the whole list in the caller's order (shortcut compare)
+    const uint32_t *planes32; int n_fast; const int32_t *reg_to_orig;   // its regular entries (reg_to_orig null: all of it)
+    const int2 *irr_meta; const uint8_t *irr_bytes; const int64_t *irr_off; int n_irr;
+    const uint8_t *ext; int ext_stride; const uint8_t *ext_len, *bc_off, *bc_len;
+    int tie, shortcut;
+    int32_t *hit; int8_t *ed; int8_t *end; uint8_t *flags;
+};
+struct GenericShared {
+    unsigned long long mn[2][kMaxK + 1];
+    uint32_t xh[kGenericMax], xl[kGenericMax], v[kGenericMax], peq[4];
+    int exact;
+    uint8_t text[kGenericMax];
+};
+
+template <int K>
+__device__ __forceinline__ void generic_row_wg(const GenericArgs &a, int r, GenericShared &sh) {
+    const int tid = threadIdx.x;
+    const int len = a.ext_len[r], off = a.bc_off[r], bl = a.bc_len[r];
+    const uint8_t *row = a.ext + (size_t)r * a.ext_stride;
+    if (tid < kGenericMax) {
+        const uint32_t c = tid < len ? row[tid] : 0u;
+        const uint32_t code = base_code(c);
+        sh.text[tid] = (uint8_t)c;
+        sh.xh[tid] = (code & 2u) ? 0u : 0xFFFFu;
+        sh.xl[tid] = (code & 1u) ? 0u : 0xFFFFu;
+        sh.v[tid] = (tid < len && is_acgt(c)) ? 0xFFFFu : 0u;
+    }
+    if (tid < 4) sh.peq[tid] = 0u;
+    if (tid == 4) sh.exact = 0x7FFFFFFF;
+    if (tid < 2 * (kMaxK + 1)) (&sh.mn[0][0])[tid] = ~0ull;
+    __syncthreads();
+    if (len < kBcLen && tid < len && sh.v[tid]) atomicOr(&sh.peq[base_code(sh.text[tid])], 1u << tid);   // the text as the pattern
+    if (a.shortcut) {
+        for (int k = tid; k < a.n_wl; k += 256) {
+            const int64_t o = a.wl_off[k];
+            if ((int)(a.wl_off[k + 1] - o) != bl) continue;
+            bool same = true;
+            for (int i = 0; i < bl && same; ++i) same = a.wl_bytes[o + i] == sh.text[off + i];
+            if (same) atomicMin(&sh.exact, k);
+        }
+    }
+    __syncthreads();
+    if (sh.exact != 0x7FFFFFFF) {                                 // workgroup-uniform
+        if (tid == 0) { a.hit[r] = sh.exact; a.ed[r] = 0; a.end[r] = -1; a.flags[r] = (uint8_t)(kFlagExact | kFlagGeneric); }
+        __syncthreads();
+        return;
+    }
+    unsigned long long keep[K + 1][2];
+#pragma unroll
+    for (int c = 0; c <= K; ++c) { keep[c][0] = ~0ull; keep[c][1] = ~0ull; }
+    auto note = [&](int idx, int ed, int end) {
+        const unsigned long long ev = ((unsigned long long)(uint32_t)idx << 16) | ((unsigned long long)ed << 8) | (unsigned long long)(end + 1);
+#pragma unroll
+        for (int c = 0; c <= K; ++c) {
+            if (c != ed) continue;
+            if (ev < keep[c][0]) { keep[c][1] = keep[c][0]; keep[c][0] = ev; }
+            else if (ev < keep[c][1]) keep[c][1] = ev;
+        }
+    };
+    for (int sub = tid; sub < a.n_fast; sub += 256) {
+        const uint32_t p = a.planes32[sub];
+        const uint32_t bh = p & 0xFFFFu, blo = p >> 16;
+        ShiftAnd<K, 1u> A;
+        A.init();
+        int best_cnt = 0, best_end = -1;
+        if (len >= kBcLen) {                                      // the barcode is the pattern (first argument when the lengths are equal)
+            for (int j = 0; j < len; ++j) {
+                A.step((bh ^ sh.xh[j]) & (blo ^ sh.xl[j]) & sh.v[j]);
+                int cnt = 0;
+#pragma unroll
+                for (int d = 0; d <= K; ++d) cnt += (A.R[d] >> (kBcLen - 1)) & 1u;
+                if (cnt > best_cnt || (a.tie && cnt == best_cnt && cnt > 0)) { best_cnt = cnt; best_end = j; }
+            }
+        } else {                                                  // the text is shorter: it is the pattern, the barcode's characters the columns
+            const uint32_t acc = 1u << (len - 1);
+            best_cnt = len <= K ? K + 1 - len : 0;
+            for (int j = 0; j < kBcLen; ++j) {
+                A.step(sh.peq[(((bh >> j) & 1u) << 1) | ((blo >> j) & 1u)]);
+                int cnt = 0;
+#pragma unroll
+                for (int d = 0; d <= K; ++d) cnt += (A.R[d] & acc) != 0u;
+                if (cnt > best_cnt || (a.tie && cnt == best_cnt && cnt > 0)) { best_cnt = cnt; best_end = j; }
+            }
+        }
+        const int ed = K + 1 - best_cnt;
+        if (ed <= K) note(a.reg_to_orig ? a.reg_to_orig[sub] : sub, ed, best_end);
+    }
+    for (int k = tid; k < a.n_irr; k += 256) {
+        int end;
+        const int ed = dev_sub_edit_distance(a.irr_bytes + a.irr_off[k], a.irr_meta[k].x, row, len, K, a.tie, end);
+        if (ed <= K) note(a.irr_meta[k].y, ed, end);
+    }
+#pragma unroll
+    for (int c = 0; c <= K; ++c) if (keep[c][0] != ~0ull) atomicMin(&sh.mn[0][c], keep[c][0]);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c <= K; ++c) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            if (keep[c][t] != ~0ull && keep[c][t] != sh.mn[0][c]) atomicMin(&sh.mn[1][c], keep[c][t]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long ev[2 * (K + 1)];
+        int nev = 0;
+#pragma unroll
+        for (int c = 0; c <= K; ++c) {
+            if (sh.mn[0][c] != ~0ull) ev[nev++] = sh.mn[0][c];
+            if (sh.mn[1][c] != ~0ull) ev[nev++] = sh.mn[1][c];
+        }
+        for (int x = 1; x < nev; ++x) {                           // whitelist order = order of the words (index in the top bits)
+            const unsigned long long v = ev[x];
+            int y = x - 1;
+            while (y >= 0 && ev[y] > v) { ev[y + 1] = ev[y]; --y; }
+            ev[y + 1] = v;
+        }
+        int best = K, hit = kHitNone, hit_end = -1;
+        bool done = false;
+        for (int x = 0; x < nev; ++x)
+            fold_update((int)((ev[x] >> 8) & 0xFFu), (int)(ev[x] & 0xFFu) - 1, (int)(ev[x] >> 16), best, hit, hit_end, done);
+        a.hit[r] = hit >= 0 ? hit : -1;
+        a.ed[r] = (int8_t)best;
+        a.end[r] = (int8_t)(hit >= 0 ? hit_end : -1);
+        a.flags[r] = (uint8_t)(kFlagGeneric | (hit == kHitAmbiguous ? kFlagAmbig : 0u));
+    }
+    __syncthreads();                                              // the shared state is reused by the workgroup's next row
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_generic_rows(GenericArgs a, const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr) {
+    __shared__ GenericShared sh;
+    const int n_list = *n_list_ptr;
+    for (int g = blockIdx.x; g < n_list; g += gridDim.x) generic_row_wg<K>(a, list[g], sh);
+}
+
 // The two rare-row scans behind the pair-seeded kernels as ONE launch: hand-over rows (redo_list: candidate-list
 // overflow, short-text pools) through the ordered filtered scan, then irregular rows (gen_list) through the byte-wise
-// scan.  The two lists are disjoint and both are almost always empty, so what this saves is a launch and the idle gap
+// scan (a workgroup per row, generic_row_wg).  The two lists are disjoint and both are almost always empty, so what this saves is a launch and the idle gap
 // in front of it (~3-4 us of a ~100 us step).  Small persistent grid: workgroups stride over both lists.
 __global__ __launch_bounds__(256) void k_pair_tail(
     const uint4 *__restrict__ grams, const uint32_t *__restrict__ planes32, int n_blk, int n_wl,
-    const uint8_t *__restrict__ wl_bytes, const int64_t *__restrict__ wl_off,
-    const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
-    const uint8_t *__restrict__ bc_off, const uint8_t *__restrict__ bc_len,
     const int32_t *__restrict__ redo_list, const int32_t *__restrict__ n_redo_ptr,
-    const int32_t *__restrict__ gen_list, const int32_t *__restrict__ n_gen_ptr, int max_ed, int tie, int shortcut,
-    int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
+    const int32_t *__restrict__ gen_list, const int32_t *__restrict__ n_gen_ptr, GenericArgs a) {
     __shared__ uint32_t fifo[kQCap][256];
+    __shared__ GenericShared sh;
     const int n_redo = *n_redo_ptr, n_gen = *n_gen_ptr;
     for (int b = blockIdx.x; b * 256 < n_redo; b += gridDim.x)
-        scan_filtered_block<2>(b, n_redo, fifo, grams, planes32, n_blk, n_wl, ext, ext_stride, ext_len, redo_list, tie,
-                               hit_out, ed_out, end_out, flags_out);
-    scan_generic_rows(blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, n_gen, wl_bytes, wl_off, n_wl, ext, ext_stride,
-                      ext_len, bc_off, bc_len, gen_list, max_ed, tie, shortcut, hit_out, ed_out, end_out, flags_out);
+        scan_filtered_block<2>(b, n_redo, fifo, grams, planes32, n_blk, n_wl, a.ext, a.ext_stride, a.ext_len, redo_list, a.tie,
+                               a.hit, a.ed, a.end, a.flags);
+    for (int g = blockIdx.x; g < n_gen; g += gridDim.x) generic_row_wg<2>(a, gen_list[g], sh);
 }
 
 // Mixed whitelists: a list with a FEW entries outside the packed shape (not 16 nt, or not all ACGT) keeps the fast path.

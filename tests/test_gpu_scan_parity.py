@@ -131,6 +131,57 @@ def test_irregular_rows(engine, oracle):
     assert t["rows_generic"] > 0 and t["rows_bitparallel"] > 0
 
 
+@pytest.mark.parametrize("mixed", [False, True], ids=["regular_list", "mixed_list"])
+@pytest.mark.parametrize("tie", [0, 1])
+@pytest.mark.parametrize("max_ed", [0, 1, 2, 3])
+def test_irregular_rows_every_kind(engine, oracle, max_ed, tie, mixed):
+    """The workgroup-per-row scan of irregular rows: N / lower case / other bytes anywhere, putative barcodes of 1..28 nt,
+    extensions of 1..32 columns (shorter than the barcodes: the text becomes the pattern; shorter than max_ed: within
+    reach of everything), barcode at odd offsets, exact copies of whitelist entries inside irregular rows (the shortcut),
+    against an all-regular and a mixed whitelist."""
+    rows, wl = _synthetic(1600, 250, err=3.0, seed=91)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    wl_list = [w.tobytes() for w in wl]
+    if mixed:
+        wl_list.insert(7, wl_list[3][:15])
+        wl_list.insert(100, wl_list[50] + b"AC")
+        wl_list.append(wl_list[9][:6] + b"N" + wl_list[9][7:])
+    rng = np.random.default_rng(6)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    n = ext.shape[0]
+    for r in range(n):
+        if bl[r] == 0:
+            continue
+        k = r % 12
+        if k == 0:
+            ext[r, rng.integers(0, 20)] = ord("N")
+        elif k == 1:
+            ext[r, rng.integers(0, 20)] |= 0x20
+        elif k == 2:                                # long extension: 5-nt flanks kept by some other producer
+            L = int(rng.integers(21, 33)); ext[r, 20:L] = acgt[rng.integers(0, 4, L - 20)]; el[r] = L
+        elif k == 3:                                # barcode of 10 nt at the start of a 10-column text: the text is the pattern
+            el[r] = 10; bo[r] = 0; bl[r] = 10
+        elif k == 4:                                # two columns: shorter than max_ed 2 and 3
+            el[r] = 2; bo[r] = 0; bl[r] = 2
+        elif k == 5:                                # one column
+            el[r] = 1; bo[r] = 0; bl[r] = 1
+        elif k == 6:                                # 28-nt putative barcode
+            ext[r, 2:30] = np.tile(ext[r, 2:18], 2)[:28]; el[r] = 32; bl[r] = 28
+        elif k == 7:                                # 15 columns, an N inside
+            el[r] = 15; bo[r] = 0; bl[r] = 15; ext[r, 4] = ord("N")
+        elif k == 8:                                # an exact copy of an entry behind an N flank: the shortcut inside an irregular row
+            w = np.frombuffer(wl_list[int(rng.integers(0, len(wl_list)))], dtype=np.uint8)
+            ext[r, :] = 0; ext[r, 0] = ord("N"); ext[r, 1] = ord("A"); ext[r, 2:2 + w.size] = w
+            ext[r, 2 + w.size:4 + w.size] = acgt[rng.integers(0, 4, 2)]; el[r] = 4 + w.size; bo[r] = 2; bl[r] = w.size
+        elif k == 9:                                # 16-column text, barcode 14
+            el[r] = 16; bo[r] = 1; bl[r] = 14
+    ext[np.arange(ext.shape[1])[None, :] >= el[:, None]] = 0
+    hit, ed, end, flags = _compare(engine, oracle, ext, el, bo, bl, wl_list, max_ed, tie)
+    t = engine.timing(0)
+    assert t["rows_generic"] > 700 and t["rows_bitparallel"] > 50
+    assert ((flags & _lib.BZ_F_EXACT) != 0)[np.arange(n) % 12 == 8].sum() > 50
+
+
 @pytest.mark.parametrize("scan_mode", **MODES)
 def test_bytes_past_the_text_are_ignored(engine, oracle, scan_mode):
     """The C ABI gives a row ext_len bytes; whatever the caller's buffer holds behind them (here: random ACGT, N and

@@ -485,18 +485,16 @@ int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed
     }
     if (prof) HIP_TRY(hipEventRecord(s.ev[2], s.stream));
     if (!s.tail_done) {
-        if (h->wl_regular && max_ed <= bz::kMaxK) {
-            // irregular rows against a list with the fast-path structures: a workgroup per row, bit-parallel per entry
+        if (h->wl_regular && max_ed <= bz::kGenericMaxK) {
+            // irregular rows (every row when max_ed is 4..8) against a list with the fast-path structures: a workgroup per
+            // row, bit-parallel per entry
             const dim3 ggrid(std::min(n, 4 * h->n_cu));
             const bz::GenericArgs ga = generic_args(h, s);
-            switch (max_ed) {
-                case 0: hipLaunchKernelGGL(bz::k_generic_rows<0>, ggrid, dim3(256), 0, s.stream, ga, s.d_gen, s.d_counters + 1); break;
-                case 1: hipLaunchKernelGGL(bz::k_generic_rows<1>, ggrid, dim3(256), 0, s.stream, ga, s.d_gen, s.d_counters + 1); break;
-                case 2: hipLaunchKernelGGL(bz::k_generic_rows<2>, ggrid, dim3(256), 0, s.stream, ga, s.d_gen, s.d_counters + 1); break;
-                default: hipLaunchKernelGGL(bz::k_generic_rows<3>, ggrid, dim3(256), 0, s.stream, ga, s.d_gen, s.d_counters + 1); break;
-            }
+#define BZ_GEN(K) case K: hipLaunchKernelGGL(bz::k_generic_rows<K>, ggrid, dim3(256), 0, s.stream, ga, s.d_gen, s.d_counters + 1); break
+            switch (max_ed) { BZ_GEN(0); BZ_GEN(1); BZ_GEN(2); BZ_GEN(3); BZ_GEN(4); BZ_GEN(5); BZ_GEN(6); BZ_GEN(7); BZ_GEN(8); }
+#undef BZ_GEN
         } else {
-            // any list, any max_ed: one lane per row, byte-wise DP over the whole list (slow; irregular lists and max_ed > 3 only)
+            // any list, any max_ed: one lane per row, byte-wise DP over the whole list (slow; irregular lists and max_ed > 8 only)
             hipLaunchKernelGGL(bz::k_scan_generic, dim3(std::min((n + 63) / 64, 16 * h->n_cu)), dim3(64), 0, s.stream, h->d_wl_bytes, h->d_wl_off, (int)h->n_wl,
                                s.d_ext, s.stride, s.d_len, s.d_off, s.d_bcl, s.d_gen, s.d_counters + 1, max_ed, h->tie_rule,
                                h->shortcut, s.d_hit, s.d_ed, s.d_end, s.d_flags);

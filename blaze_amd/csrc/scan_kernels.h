@@ -1344,7 +1344,7 @@ __global__ void k_scan_generic(const uint8_t *__restrict__ wl_bytes, const int64
 
 // ------------------------------------------------------------------------------------------
 // Irregular ROWS (N or lower case somewhere in the extension, a putative barcode that is not 16 nt, an extension longer
-// than 20) against a whitelist that has the fast-path structures (all regular, or mixed), max_ed <= 3.
+// than 20; every row when max_ed is 4..8) against a whitelist that has the fast-path structures (all regular, or mixed).
 // k_scan_generic above gives such a row ONE lane that walks the whole list with the byte-wise DP: ~0.24 ms per pair with
 // the DP column in scratch memory, 1.2 s for a 5,000-entry list, and a step lasts as long as its slowest lane -- ten such
 // rows in a batch of a million made the step 12,000 times longer.  Here a WORKGROUP takes the row: its lanes stride over
@@ -1363,8 +1363,9 @@ struct GenericArgs {
     int tie, shortcut;
     int32_t *hit; int8_t *ed; int8_t *end; uint8_t *flags;
 };
+constexpr int kGenericMaxK = 8;                                   // generic_row_wg is instantiated for max_ed 0..8
 struct GenericShared {
-    unsigned long long mn[2][kMaxK + 1];
+    unsigned long long mn[2][kGenericMaxK + 1];
     uint32_t xh[kGenericMax], xl[kGenericMax], v[kGenericMax], peq[4];
     int exact;
     uint8_t text[kGenericMax];
@@ -1385,7 +1386,7 @@ __device__ __forceinline__ void generic_row_wg(const GenericArgs &a, int r, Gene
     }
     if (tid < 4) sh.peq[tid] = 0u;
     if (tid == 4) sh.exact = 0x7FFFFFFF;
-    if (tid < 2 * (kMaxK + 1)) (&sh.mn[0][0])[tid] = ~0ull;
+    if (tid < 2 * (kGenericMaxK + 1)) (&sh.mn[0][0])[tid] = ~0ull;
     __syncthreads();
     if (len < kBcLen && tid < len && sh.v[tid]) atomicOr(&sh.peq[base_code(sh.text[tid])], 1u << tid);   // the text as the pattern
     if (a.shortcut) {

@@ -182,6 +182,20 @@ def test_irregular_rows_every_kind(engine, oracle, max_ed, tie, mixed):
     assert ((flags & _lib.BZ_F_EXACT) != 0)[np.arange(n) % 12 == 8].sum() > 50
 
 
+@pytest.mark.parametrize("max_ed", [4, 5, 8, 9])
+def test_max_ed_above_the_packed_kernels(engine, oracle, max_ed):
+    """--max-edit-distance above 3: no row takes the packed kernels; 4..8 go through the workgroup-per-row scan, 9 through
+    the one-lane byte-wise scan.  Near matches are everywhere at these cut-offs, so the fold's tie cascade is exercised."""
+    rows, wl = _synthetic(700, 120, err=4.0, seed=95)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    ext[5, 3] = ord("N")
+    for tie in (0, 1):
+        hit, ed, end, flags = _compare(engine, oracle, ext, el, bo, bl, [w.tobytes() for w in wl], max_ed, tie)
+    t = engine.timing(0)
+    assert t["rows_bitparallel"] == 0 and t["rows_generic"] > 400
+    assert ((hit >= 0) & ((flags & _lib.BZ_F_EXACT) == 0)).sum() > 50
+
+
 @pytest.mark.parametrize("scan_mode", **MODES)
 def test_bytes_past_the_text_are_ignored(engine, oracle, scan_mode):
     """The C ABI gives a row ext_len bytes; whatever the caller's buffer holds behind them (here: random ACGT, N and

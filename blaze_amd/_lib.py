@@ -24,7 +24,7 @@ EXPORTS = [
     "bz_assign_run", "bz_assign_fetch", "bz_slot_sync", "bz_slot_timing", "bz_sub_edit_distance",
     "bz_edit_distance", "bz_counts_reset", "bz_counts_get", "bz_comm_unique_id", "bz_comm_init",
     "bz_comm_allreduce_counts", "bz_comm_allreduce_f64", "bz_comm_destroy", "bz_valu_peak_probe", "bz_assign_files", "bz_far_from_all", "bz_putative_bc",
-    "bz_putative_bc_files", "bz_assign_files_from", "bz_fastq_count_reads", "bz_assign_device_noalloc", "bz_comm_allreduce_i64", "bz_host_alloc", "bz_host_free", "bz_assign_submit_pinned", "bz_gzip_fastq_bound", "bz_gzip_fastq_member",
+    "bz_putative_bc_files", "bz_assign_files_from", "bz_fastq_count_reads", "bz_assign_device_noalloc", "bz_comm_allreduce_i64", "bz_host_alloc", "bz_host_free", "bz_assign_submit_pinned", "bz_gzip_fastq_bound", "bz_gzip_fastq_member", "bz_fastq_first_read_id", "bz_csv_locate_read", "bz_assign_files_at",
 ]
 
 
@@ -84,6 +84,9 @@ def load():
         "bz_putative_bc_files": ([ctypes.POINTER(p), i, ctypes.POINTER(cp), i, cp, i, i, i, i, i64, i, ctypes.POINTER(i64)], i),
         "bz_assign_files_from": ([ctypes.POINTER(p), i, ctypes.POINTER(cp), i, cp, i64, cp, i, i, i, i, i64, i, ctypes.POINTER(i64)], i),
         "bz_fastq_count_reads": ([cp, ctypes.POINTER(i64)], i),
+        "bz_fastq_first_read_id": ([cp, p, i, pi], i),
+        "bz_csv_locate_read": ([cp, cp, i, ctypes.c_double, ctypes.POINTER(i64)], i),
+        "bz_assign_files_at": ([ctypes.POINTER(p), i, ctypes.POINTER(cp), i, cp, i64, cp, i, i, i, i, i64, i, ctypes.POINTER(i64)], i),
         "bz_assign_device_noalloc": ([p, p, i, p, p, p, i64, i, p, p, p, p, p], i),
         "bz_assign_files": ([ctypes.POINTER(p), i, ctypes.POINTER(cp), i, cp, cp, i, i, i, i, i64, i, ctypes.POINTER(i64)], i),
     }

@@ -1308,9 +1308,48 @@ int bz_assign_files(bz_handle *engines, int n_engines, const char *const *fastq_
                                 device_batch_rows, n_threads, out_counts);
 }
 
+static int assign_files_impl(bz_handle *engines, int n_engines, const char *const *fastq_fns, int n_fastq, const char *putative_bc_csv,
+                             int64_t csv_skip_rows, int64_t csv_byte_offset, const char *fastq_out, int gz, int restrand, int max_ed,
+                             int batch_size, int64_t device_batch_rows, int n_threads, int64_t out_counts[4]);
+
 int bz_assign_files_from(bz_handle *engines, int n_engines, const char *const *fastq_fns, int n_fastq, const char *putative_bc_csv,
                          int64_t csv_skip_rows, const char *fastq_out, int gz, int restrand, int max_ed, int batch_size,
                          int64_t device_batch_rows, int n_threads, int64_t out_counts[4]) {
+    return assign_files_impl(engines, n_engines, fastq_fns, n_fastq, putative_bc_csv, csv_skip_rows, -1, fastq_out, gz, restrand, max_ed,
+                             batch_size, device_batch_rows, n_threads, out_counts);
+}
+
+int bz_assign_files_at(bz_handle *engines, int n_engines, const char *const *fastq_fns, int n_fastq, const char *putative_bc_csv,
+                       int64_t csv_byte_offset, const char *fastq_out, int gz, int restrand, int max_ed, int batch_size,
+                       int64_t device_batch_rows, int n_threads, int64_t out_counts[4]) {
+    if (csv_byte_offset < 0) return fail(BZ_E_ARG, "negative csv_byte_offset");
+    return assign_files_impl(engines, n_engines, fastq_fns, n_fastq, putative_bc_csv, 0, csv_byte_offset, fastq_out, gz, restrand, max_ed,
+                             batch_size, device_batch_rows, n_threads, out_counts);
+}
+
+int bz_fastq_first_read_id(const char *path, char *out, int cap, int *len) {
+    if (!path || !out || cap < 1 || !len) return fail(BZ_E_ARG, "bad arguments");
+    try {
+        const std::string id = bzio::first_fastq_id(path);
+        if ((int)id.size() >= cap) return fail(BZ_E_LIMIT, "read id of %zu bytes does not fit %d", id.size(), cap);
+        memcpy(out, id.data(), id.size());
+        out[id.size()] = 0;
+        *len = (int)id.size();
+    } catch (const std::exception &e) {
+        return fail(BZ_E_ARG, "%s", e.what());
+    }
+    return BZ_OK;
+}
+
+int bz_csv_locate_read(const char *putative_bc_csv, const char *read_id, int id_len, double hint_fraction, int64_t *byte_offset) {
+    if (!putative_bc_csv || !read_id || id_len < 0 || !byte_offset) return fail(BZ_E_ARG, "bad arguments");
+    *byte_offset = bzio::csv_locate_row(putative_bc_csv, std::string(read_id, (size_t)id_len), hint_fraction);
+    return BZ_OK;
+}
+
+static int assign_files_impl(bz_handle *engines, int n_engines, const char *const *fastq_fns, int n_fastq, const char *putative_bc_csv,
+                             int64_t csv_skip_rows, int64_t csv_byte_offset, const char *fastq_out, int gz, int restrand, int max_ed,
+                             int batch_size, int64_t device_batch_rows, int n_threads, int64_t out_counts[4]) {
     if (csv_skip_rows < 0) return fail(BZ_E_ARG, "negative csv_skip_rows");
     if (!engines || n_engines < 1 || !fastq_fns || n_fastq < 0 || !putative_bc_csv || !fastq_out) return fail(BZ_E_ARG, "bad file arguments");
     if (batch_size < 1 || device_batch_rows < 1 || n_threads < 1) return fail(BZ_E_ARG, "batch_size, device_batch_rows and n_threads must be >= 1");
@@ -1324,6 +1363,7 @@ int bz_assign_files_from(bz_handle *engines, int n_engines, const char *const *f
     job.gz = gz != 0; job.restrand = restrand != 0; job.max_ed = max_ed; job.batch_size = batch_size;
     job.n_threads = n_threads; job.device_batch_rows = std::min<int64_t>(device_batch_rows, (int64_t)1 << 24);
     job.csv_skip_rows = csv_skip_rows;
+    job.csv_byte_offset = csv_byte_offset;
     // How the `.gz` members are compressed.  The reference's gzip.compress is zlib level 9; the decompressed stream is the
     // contract (the compressed bytes carry a wall-clock mtime and are never reproducible).  Default 0 = the
     // FASTQ-aware block encoder of fastq_deflate.h (1.8 % larger than level 9, ~30x faster per host thread); 1..9 = zlib

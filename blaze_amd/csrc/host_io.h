@@ -79,7 +79,7 @@ class LineSource {
 // lives as long as the source object, which the job keeps until its last chunk is written
 class MmapLines : public LineSource {
    public:
-    explicit MmapLines(const std::string &path) {
+    explicit MmapLines(const std::string &path, size_t start = 0) {
         fd_ = open(path.c_str(), O_RDONLY);
         if (fd_ < 0) throw std::runtime_error("cannot open " + path);
         struct stat st;
@@ -89,6 +89,8 @@ class MmapLines : public LineSource {
             void *m = mmap(nullptr, size_, PROT_READ | PROT_WRITE, MAP_PRIVATE, fd_, 0);
             if (m == MAP_FAILED) { close(fd_); fd_ = -1; throw std::runtime_error("cannot map " + path); }
             base_ = (char *)m;
+            start_ = std::min(start, size_);                      // a rank of a sharded run starts at ITS first row of the table
+            at_.store(start_, std::memory_order_relaxed);
             madvise(base_, size_, MADV_SEQUENTIAL);
             // The scan below runs at memchr speed only over pages that are already mapped: taking the page faults itself
             // (one per 64 KB of page cache) was most of the reader thread's time.  A helper maps the pages ahead of the
@@ -119,7 +121,7 @@ class MmapLines : public LineSource {
     static constexpr size_t kPopulateStep = (size_t)8 << 20, kPopulateLead = (size_t)256 << 20;
     void populate() {
         bool by_madvise = true;
-        for (size_t off = 0; off < size_ && !stop_.load(std::memory_order_relaxed); off += kPopulateStep) {
+        for (size_t off = start_ / kPopulateStep * kPopulateStep; off < size_ && !stop_.load(std::memory_order_relaxed); off += kPopulateStep) {
             while (off > at_.load(std::memory_order_relaxed) + kPopulateLead) {          // far enough ahead of the scan
                 if (stop_.load(std::memory_order_relaxed)) return;
                 usleep(200);
@@ -134,7 +136,7 @@ class MmapLines : public LineSource {
     }
     int fd_ = -1;
     char *base_ = nullptr;
-    size_t size_ = 0;
+    size_t size_ = 0, start_ = 0;
     std::atomic<size_t> at_{0};                                   // scan position (the helper stays kPopulateLead ahead at most)
     std::atomic<bool> stop_{false};
     std::thread populator_;
@@ -370,6 +372,56 @@ inline int64_t count_fastq_reads(const std::string &path) {
     return (lines + 3) / 4;
 }
 
+// ---- a rank of a file-sharded run finds ITS rows of putative_bc.csv without counting anybody's reads ---------------
+// The table has one row per read in the order of the FASTQ files (parser.py:35-47, main.py:361-364), so the rows of a
+// rank's files start at the row whose read_id is the id of the first read of its first non-empty file.  Counting the
+// reads of all earlier files finds that row too, but reads every FASTQ byte a second time (gzipped files: inflates
+// them twice); a search for "\n<id>," in the mapped table, outward from where the row would be if reads were spread
+// evenly over the bytes, touches a few megabytes.
+inline Span fastq_id(Span line);
+inline std::string first_fastq_id(const std::string &path) {
+    auto src = open_lines(path);
+    Arena a;
+    Span s;
+    if (!src->next(a, s)) return std::string();
+    const Span id = fastq_id(s);
+    return std::string(id.p, id.len);
+}
+
+// byte offset of the row whose first cell is `id` in the PLAIN csv at `path`, or -1 (not found, or the table is gzipped)
+inline int64_t csv_locate_row(const std::string &path, const std::string &id, double hint) {
+    if (ends_with_gz(path) || id.empty()) return -1;
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return -1;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0) { close(fd); return -1; }
+    const size_t size = (size_t)st.st_size;
+    void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) { close(fd); return -1; }
+    const char *base = (const char *)m;
+    const std::string needle = "\n" + id + ",";
+    const size_t window = (size_t)16 << 20, overlap = needle.size();
+    const size_t mid = (size_t)(std::min(1.0, std::max(0.0, hint)) * (double)size);
+    int64_t found = -1;
+    auto look = [&](size_t lo, size_t hi) {                       // [lo, hi) plus the overlap behind it
+        hi = std::min(size, hi + overlap);
+        if (lo >= hi) return false;
+        const void *hit = memmem(base + lo, hi - lo, needle.data(), needle.size());
+        if (hit) found = (int64_t)((const char *)hit - base) + 1;
+        return hit != nullptr;
+    };
+    for (size_t k = 0;; ++k) {
+        const size_t up_lo = mid + k * window, dn_hi = mid > k * window ? mid - k * window : 0;
+        const bool up = up_lo < size, dn = dn_hi > 0;
+        if (!up && !dn) break;
+        if (up && look(up_lo, up_lo + window)) break;
+        if (dn && look(dn_hi > window ? dn_hi - window : 0, dn_hi)) break;
+    }
+    munmap(m, size);
+    close(fd);
+    return found;
+}
+
 // seconds spent per stage of a file job (BLAZE_AMD_IO_TIMING=1 prints them)
 struct StageClock {
     double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -463,6 +515,7 @@ struct Job {
     int max_ed = 2, batch_size = 1000, n_threads = 8, gz_level = 0;   // gz_level: 0 = fastq_deflate.h, 1..9 = zlib
     int64_t device_batch_rows = 1 << 16;
     int64_t csv_skip_rows = 0;               // rows of the table that belong to reads of earlier FASTQ files (another rank's)
+    int64_t csv_byte_offset = -1;            // or: where this rank's first row starts in the (plain) table; -1 = header + csv_skip_rows
 };
 
 struct MismatchError : std::runtime_error { using std::runtime_error::runtime_error; };
@@ -493,7 +546,11 @@ void parallel_for(int n_items, int n_threads, F &&fn) {
 // ---- reader: FASTQ records + the same number of csv lines, cut into device batches of whole reference batches --
 class ChunkReader {
    public:
-    explicit ChunkReader(const Job &job) : job_(job), csv_(open_lines(job.csv)), files_(job.fastq_fns, job.n_threads) {
+    explicit ChunkReader(const Job &job)
+        : job_(job), csv_(job.csv_byte_offset >= 0 ? std::shared_ptr<LineSource>(std::make_shared<MmapLines>(job.csv, (size_t)job.csv_byte_offset))
+                                                   : open_lines(job.csv)),
+          files_(job.fastq_fns, job.n_threads) {
+        if (job.csv_byte_offset >= 0) return;                      // positioned on this rank's first row already
         Arena tmp; Span s;
         if (!csv_->next(tmp, s)) throw std::runtime_error("putative bc csv is empty: " + job.csv);   // header (:150 `next(f)`)
         for (int64_t k = 0; k < job.csv_skip_rows; ++k) {

@@ -324,12 +324,42 @@ def part_path(fastq_out, rank: int) -> str:
     return f"{stem}.part{rank:04d}" + ('.gz' if gz else '')
 
 
+def first_read_id(path) -> str:
+    """Id of the first read of a FASTQ(.gz) file as the reference's parser takes it ('' when the file holds no read)."""
+    import ctypes
+    from . import _lib
+    buf, n = ctypes.create_string_buffer(4096), ctypes.c_int(0)
+    _lib.check(_lib.load().bz_fastq_first_read_id(os.fsencode(str(path)), buf, 4096, ctypes.byref(n)))
+    return buf.raw[:n.value].decode("latin-1")
+
+
+def locate_first_row(putative_bc_csv, fastq_fns, lo, hi):
+    """Where the rows of the files fastq_fns[lo:hi] start in the (plain) table, WITHOUT counting the reads of the files in
+    front of them: the row whose read_id is the id of the first read of the first non-empty file (searched outward from
+    where it would be if reads were spread evenly over the FASTQ bytes).  -> byte offset; 0 when those files hold no read
+    at all (nothing will be asked of the table); None when the row cannot be found (gzipped table, quoted ids)."""
+    import ctypes
+    from . import _lib
+    rid, first = "", lo
+    while first < hi and not rid:
+        rid = first_read_id(fastq_fns[first])
+        first += 1
+    if not rid:
+        return 0
+    sizes = [os.path.getsize(f) for f in fastq_fns]
+    hint = sum(sizes[:first - 1]) / float(sum(sizes) or 1)
+    off = ctypes.c_int64(-1)
+    enc = rid.encode("latin-1")
+    _lib.check(_lib.load().bz_csv_locate_read(os.fsencode(str(putative_bc_csv)), enc, len(enc), hint, ctypes.byref(off)))
+    return None if off.value < 0 else int(off.value)
+
+
 def native_run_rank(putative_bc_csv, whitelsit_csv, max_ed, n_process, batchsize, restrand=True, device=None):
     """What one rank does with its files in assign_read_sharded: the native device pipeline (bz_assign_files_from) on this
     process's GPU, `csv_skip_rows` rows of the table skipped.  -> run_rank(fns, out, csv_skip_rows) = (assigned, seen)."""
     from . import read_assignment as ra
 
-    def run_rank(fns, out, csv_skip_rows):
+    def run_rank(fns, out, csv_skip_rows, csv_byte_offset=None):
         whitelist = []
         with open(whitelsit_csv, 'r') as f:
             for line in f:
@@ -340,7 +370,8 @@ def native_run_rank(putative_bc_csv, whitelsit_csv, max_ed, n_process, batchsize
         ra._ensure_whitelist(eng, ordered)
         threads = max(1, min(int(n_process or 1), os.cpu_count() or 1, 256))
         return ra._assign_files_native([eng], fns, putative_bc_csv, out, str(out).endswith('.gz'), restrand, max_ed, batchsize,
-                                       ra.DEVICE_BATCH_ROWS, threads, csv_skip_rows=csv_skip_rows)
+                                       ra.DEVICE_BATCH_ROWS, threads, csv_skip_rows=csv_skip_rows or 0, csv_byte_offset=csv_byte_offset)
+    run_rank.takes_byte_offset = True
     return run_rank
 
 
@@ -357,6 +388,22 @@ def assign_read_sharded(comm, fastq_fns, fastq_out, putative_bc_csv, whitelsit_c
     fastq_fns = [str(f) for f in fastq_fns]
     spans = partition_files([os.path.getsize(f) for f in fastq_fns], comm.world)
     lo, hi = spans[comm.rank]
+    part = part_path(fastq_out, comm.rank)
+    if run_rank is None:
+        run_rank = native_run_rank(putative_bc_csv, whitelsit_csv, max_ed, n_process, batchsize, restrand, device)
+    # Where do this rank's rows of the table start?  First choice: find the row of its first read in the table itself (no
+    # FASTQ byte is read twice); every rank must succeed, else all fall back to counting the reads of their own files and
+    # one all-reduce of the counts.
+    offset = None
+    if getattr(run_rank, "takes_byte_offset", False) and count_reads is count_fastq_reads and os.environ.get("BLAZE_AMD_CSV_LOCATE", "1") != "0":
+        offset = locate_first_row(putative_bc_csv, fastq_fns, lo, hi) if hi > lo else 0
+        found = comm.allreduce_sum_i64(np.array([0 if offset is None else 1], dtype=np.int64))
+        if int(found[0]) != comm.world:
+            offset = None
+    if offset is not None:
+        demul, total = run_rank(fastq_fns[lo:hi], part, None, csv_byte_offset=offset) if hi > lo else (0, 0)
+        sums = place_parts(comm, fastq_out, part, extra_sums=(demul, total))
+        return int(sums[0]), int(sums[1])
     mine = np.zeros(comm.world, dtype=np.int64)
     # counting gzipped files means inflating them: the files of this rank side by side (the native counter drops the GIL)
     from concurrent.futures import ThreadPoolExecutor
@@ -364,9 +411,6 @@ def assign_read_sharded(comm, fastq_fns, fastq_out, putative_bc_csv, whitelsit_c
         mine[comm.rank] = sum(pool.map(count_reads, fastq_fns[lo:hi]))
     per_rank = comm.allreduce_sum_i64(mine)                     # every rank's read count
     skip = int(per_rank[:comm.rank].sum())
-    part = part_path(fastq_out, comm.rank)
-    if run_rank is None:
-        run_rank = native_run_rank(putative_bc_csv, whitelsit_csv, max_ed, n_process, batchsize, restrand, device)
     demul, total = run_rank(fastq_fns[lo:hi], part, skip) if hi > lo else (0, 0)
     sums = place_parts(comm, fastq_out, part, extra_sums=(demul, total))
     return int(sums[0]), int(sums[1])

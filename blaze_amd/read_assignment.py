@@ -241,18 +241,20 @@ def _device_ids(devices):
 
 
 def _assign_files_native(engines, fastq_fns, putative_bc_csv, fastq_out, gz, restrand, max_ed, batchsize,
-                         device_batch_rows, n_threads, csv_skip_rows=0):
-    """bz_assign_files(_from): the C++ host pipeline (blaze_amd/csrc/host_io.h) around the same device scan.
-    `csv_skip_rows`: rows of the table that belong to FASTQ files in front of `fastq_fns` (another rank's)."""
+                         device_batch_rows, n_threads, csv_skip_rows=0, csv_byte_offset=None):
+    """bz_assign_files(_from / _at): the C++ host pipeline (blaze_amd/csrc/host_io.h) around the same device scan.
+    `csv_skip_rows`: rows of the table that belong to FASTQ files in front of `fastq_fns` (another rank's), or
+    `csv_byte_offset`: where this rank's first row starts in the table (dist.locate_first_row)."""
     import ctypes
     from . import _lib
     L = _lib.load()
     handles = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
     fns = (ctypes.c_char_p * len(fastq_fns))(*[os.fsencode(str(f)) for f in fastq_fns])
     counts = (ctypes.c_int64 * 4)()
-    rc = L.bz_assign_files_from(handles, len(engines), fns, len(fastq_fns), os.fsencode(str(putative_bc_csv)),
-                                int(csv_skip_rows), os.fsencode(str(fastq_out)), int(bool(gz)), int(bool(restrand)), int(max_ed),
-                                int(batchsize), int(device_batch_rows), int(n_threads), counts)
+    entry, where = (L.bz_assign_files_from, csv_skip_rows) if csv_byte_offset is None else (L.bz_assign_files_at, csv_byte_offset)
+    rc = entry(handles, len(engines), fns, len(fastq_fns), os.fsencode(str(putative_bc_csv)),
+               int(where), os.fsencode(str(fastq_out)), int(bool(gz)), int(bool(restrand)), int(max_ed),
+               int(batchsize), int(device_batch_rows), int(n_threads), counts)
     if rc == _lib.BZ_E_MISMATCH:                    # the reference's reaction, read_assignment.py:219-223
         helper.err_msg("Different order in putative bc file and input fastq!", printit=True)
         sys.exit()

@@ -212,6 +212,17 @@ int bz_assign_files(bz_handle *engines, int n_engines, const char *const *fastq_
 int bz_assign_files_from(bz_handle *engines, int n_engines, const char *const *fastq_fns, int n_fastq,
                          const char *putative_bc_csv, int64_t csv_skip_rows, const char *fastq_out, int gz, int restrand,
                          int max_ed, int batch_size, int64_t device_batch_rows, int n_threads, int64_t out_counts[4]);
+/* The same without counting anybody's reads: the rank's first row of the (plain) table is the one whose read_id is the id
+ * of the first read of its first non-empty file.  bz_fastq_first_read_id gives that id (len 0: the file holds no read),
+ * bz_csv_locate_read searches the mapped table for it outward from hint_fraction of its size (bytes of FASTQ before the
+ * rank's files / all FASTQ bytes) and gives the row's byte offset (-1: not found, or the table is gzipped: count instead),
+ * bz_assign_files_at starts the table there.  A wrong offset cannot go unnoticed: every row's read_id is compared with
+ * its read as in the reference (read_assignment.py:219-223, BZ_E_MISMATCH).  Host only but for the last. */
+int bz_fastq_first_read_id(const char *path, char *out, int cap, int *len);
+int bz_csv_locate_read(const char *putative_bc_csv, const char *read_id, int id_len, double hint_fraction, int64_t *byte_offset);
+int bz_assign_files_at(bz_handle *engines, int n_engines, const char *const *fastq_fns, int n_fastq,
+                       const char *putative_bc_csv, int64_t csv_byte_offset, const char *fastq_out, int gz, int restrand,
+                       int max_ed, int batch_size, int64_t device_batch_rows, int n_threads, int64_t out_counts[4]);
 /* Reads in one FASTQ(.gz) file as helper.fastq_parser (helper.py:292-301) would yield them (lines / 4); host only. */
 int bz_fastq_count_reads(const char *path, int64_t *n_reads);
 

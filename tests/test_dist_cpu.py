@@ -315,3 +315,41 @@ def test_place_parts_offsets_headers_and_empty_ranks(tmp_path):
     os.remove(out)
     out = _place(tmp_path, [None, None], drop_header=True, create_empty=False)
     assert not os.path.exists(out)
+
+
+def test_locate_first_row_of_a_ranks_files(tmp_path):
+    """A rank finds where its rows of putative_bc.csv start from the id of its first read (host only): every partition
+    of the files, empty files in front, the first and the last row, a gzipped table / an unknown id -> None."""
+    import gzip
+    import numpy as np
+    from blaze_amd import dist
+    rng = np.random.default_rng(3)
+    reads = [0, 700, 0, 1500, 1, 0, 3000, 40]
+    fns, rows, starts, k = [], ["read_id,putative_bc,putative_bc_min_q,putative_umi,polyT_end,pre_bc_flanking,post_umi_flanking\n"], [], 0
+    for f, n in enumerate(reads):
+        fn = tmp_path / (f"f{f}.fastq" + (".gz" if f == 3 else ""))
+        body = "".join(f"@read-{f}-{i}-{int(rng.integers(1 << 30)):x} runid=x\nACGT\n+\nIIII\n" for i in range(n))
+        if f == 3:
+            with gzip.open(fn, "wt") as g:
+                g.write(body)
+        else:
+            fn.write_text(body)
+        fns.append(str(fn))
+        starts.append(len("".join(rows)))
+        rows += [line[1:].split()[0] + ",ACGTACGTACGTACGT,15,ACGTACGTACGT,300,ACGTA,TTTTT\n" for line in body.splitlines()[::4]]
+    csv = tmp_path / "putative_bc.csv"
+    csv.write_text("".join(rows))
+    assert dist.first_read_id(fns[0]) == "" and dist.first_read_id(fns[1]).startswith("read-1-0-")
+    assert dist.first_read_id(fns[3]).startswith("read-3-0-")                      # gzipped file
+    for world in (1, 2, 3, 5, 8):
+        for lo, hi in dist.partition_files([os.path.getsize(f) for f in fns], world):
+            off = dist.locate_first_row(str(csv), fns, lo, hi)
+            first = next((f for f in range(lo, hi) if reads[f]), None)
+            assert off == (0 if first is None else starts[first]), (world, lo, hi)
+    # the hint may be far off: files whose bytes say nothing about their reads
+    assert dist.locate_first_row(str(csv), fns, 7, 8) == starts[7] and dist.locate_first_row(str(csv), fns, 0, 2) == starts[1]
+    with gzip.open(tmp_path / "t.csv.gz", "wt") as g:
+        g.write("".join(rows))
+    assert dist.locate_first_row(str(tmp_path / "t.csv.gz"), fns, 1, 2) is None   # not seekable: the caller counts instead
+    (tmp_path / "other.fastq").write_text("@nobody\nA\n+\nI\n")
+    assert dist.locate_first_row(str(csv), [str(tmp_path / "other.fastq")], 0, 1) is None

@@ -243,8 +243,9 @@ class _ThreadComm:
         return out
 
 
+@pytest.mark.parametrize("locate", [True, False], ids=["located_row", "counted_reads"])
 @pytest.mark.parametrize("gz", [False, True])
-def test_file_shards_concatenate_to_the_single_run(tmp_path, gz):
+def test_file_shards_concatenate_to_the_single_run(tmp_path, gz, locate):
     """Reads sharded by FILE over ranks (dist.assign_read_sharded -> bz_assign_files_from with the csv rows of the
     earlier files skipped, every rank placing its own part at its offset): the output is the single-process output."""
     import threading
@@ -263,9 +264,10 @@ def test_file_shards_concatenate_to_the_single_run(tmp_path, gz):
     device_lock = threading.Lock()
     native = dist.native_run_rank(pc, pw, 2, 4, 300, True, 0)
 
-    def run_rank(files, part, skip):
+    def run_rank(files, part, skip, csv_byte_offset=None):
         with device_lock:
-            return native(files, part, skip)
+            return native(files, part, skip, csv_byte_offset=csv_byte_offset)
+    run_rank.takes_byte_offset = locate            # True: every rank finds its first row in the table; False: reads are counted
     res, errs = {}, []
 
     def rank_main(rank):

@@ -20,6 +20,7 @@
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -321,7 +322,70 @@ class FastqFiles {
             cv_.notify_all();
         }
     }
+    // Whole-buffer inflate through the system's libdeflate when the host has one (dlopen, no header needed: four C symbols
+    // with a stable ABI): 2-3x zlib's rate on gzipped FASTQ.  Member after member (`_ex` reports the input it consumed);
+    // anything it does not take at face value (not gzip, trailing bytes, damaged data, > 2 GiB members) is left to the
+    // zlib path below, whose behaviour is then what it always was.  BLAZE_AMD_LIBDEFLATE=0 turns it off.
+    struct LibDeflate {
+        void *(*alloc)() = nullptr;
+        void (*release)(void *) = nullptr;
+        int (*gunzip)(void *, const void *, size_t, void *, size_t, size_t *, size_t *) = nullptr;
+        static const LibDeflate *get() {
+            static const LibDeflate *inst = []() -> const LibDeflate * {
+                void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+                if (!h) return nullptr;
+                static LibDeflate l;
+                l.alloc = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
+                l.release = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+                l.gunzip = (int (*)(void *, const void *, size_t, void *, size_t, size_t *, size_t *))dlsym(h, "libdeflate_gzip_decompress_ex");
+                return (l.alloc && l.release && l.gunzip) ? &l : nullptr;
+            }();
+            return inst;
+        }
+    };
+    static bool inflate_whole(const std::string &path, std::unique_ptr<char[]> &out, size_t &size) {
+        const char *e = getenv("BLAZE_AMD_LIBDEFLATE");
+        const LibDeflate *ld = (e && e[0] == '0') ? nullptr : LibDeflate::get();
+        if (!ld) return false;
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size < 18) { close(fd); return false; }
+        const size_t in_size = (size_t)st.st_size;
+        void *m = mmap(nullptr, in_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) return false;
+        const unsigned char *in = (const unsigned char *)m;
+        void *d = ld->alloc();
+        bool ok = d != nullptr;
+        // ISIZE of the last member is the whole size for the usual one-member file; several members grow the buffer
+        const size_t isize = (size_t)in[in_size - 4] | (size_t)in[in_size - 3] << 8 | (size_t)in[in_size - 2] << 16 | (size_t)in[in_size - 1] << 24;
+        size_t cap = std::max<size_t>(isize, in_size * 3) + 4096, n = 0, pos = 0;
+        std::unique_ptr<char[]> buf;
+        if (ok) buf.reset(new char[cap]);
+        while (ok && pos < in_size) {
+            size_t used = 0, made = 0;
+            const int rc = ld->gunzip(d, in + pos, in_size - pos, buf.get() + n, cap - n, &used, &made);
+            if (rc == 3) {                                        // LIBDEFLATE_INSUFFICIENT_SPACE: the member starts over in a larger buffer
+                std::unique_ptr<char[]> bigger(new char[cap * 2]);
+                memcpy(bigger.get(), buf.get(), n);
+                buf.swap(bigger);
+                cap *= 2;
+                continue;
+            }
+            if (rc != 0 || used == 0) { ok = false; break; }
+            n += made; pos += used;
+        }
+        if (d) ld->release(d);
+        munmap(m, in_size);
+        if (!ok) return false;
+        out = std::move(buf);
+        size = n;
+        return true;
+    }
     static size_t inflate_file(const std::string &path, std::unique_ptr<char[]> &out) {
+        size_t whole = 0;
+        if (inflate_whole(path, out, whole)) return whole;
         gzFile f = gzopen(path.c_str(), "rb");                  // multi-member files and plain text behind a .gz name included
         if (!f) throw std::runtime_error("cannot open " + path);
         gzbuffer(f, 1 << 20);

@@ -294,7 +294,7 @@ def test_file_shards_concatenate_to_the_single_run(tmp_path, gz, locate):
 def test_many_gzipped_inputs_prefetch_pool(tmp_path, monkeypatch):
     """A nanopore run's shape: many small `.fastq.gz` files (some empty, one plain).  The pool that inflates the next
     files ahead of the reader (host_io.h: FastqFiles) gives the bytes of the streaming reader and of the pandas host,
-    with a roomy and with a one-megabyte budget, for step 3 and for the stage-1 table."""
+    with a roomy and with a one-megabyte budget, through libdeflate and through zlib, for step 3 and for the stage-1 table."""
     from blaze_amd import putative_bc
     n = 6000
     fns, pc, pw, bounds = _make_files(tmp_path, n, 300, seed=17, n_files=12, quirks=False)
@@ -304,8 +304,14 @@ def test_many_gzipped_inputs_prefetch_pool(tmp_path, monkeypatch):
             gz_fns.append(fn)
             continue
         raw = open(fn, "rb").read()
-        with gzip.open(fn + ".gz", "wb", compresslevel=1) as f:
-            f.write(raw)
+        if k == 2:                                   # two members in one file (cat a.gz b.gz), cut in the middle of a line
+            blob = gzip.compress(raw[:len(raw) // 3], 1) + gzip.compress(raw[len(raw) // 3:], 9)
+        elif k == 7:                                 # zero padding after the member (tape blocks): gzip and zlib read past it
+            blob = gzip.compress(raw, 1) + b"\0" * 64
+        else:
+            blob = gzip.compress(raw, 1)
+        with open(fn + ".gz", "wb") as f:
+            f.write(blob)
         gz_fns.append(fn + ".gz")
     empty = str(tmp_path / "none.fastq.gz")
     with gzip.open(empty, "wb") as f:
@@ -315,8 +321,9 @@ def test_many_gzipped_inputs_prefetch_pool(tmp_path, monkeypatch):
     want = ra.assign_read(fastq_out=str(tmp_path / "pandas.fastq"), n_process=1, host="python", **kw)
     ref = (tmp_path / "pandas.fastq").read_bytes()
     eng = ra.get_engine(0)
-    for name, env in (("pool", {}), ("tight", {"BLAZE_AMD_GZ_PREFETCH_MB": "1"}), ("stream", {"BLAZE_AMD_GZ_PREFETCH": "0"})):
-        for k in ("BLAZE_AMD_GZ_PREFETCH_MB", "BLAZE_AMD_GZ_PREFETCH"):
+    for name, env in (("pool", {}), ("tight", {"BLAZE_AMD_GZ_PREFETCH_MB": "1"}), ("stream", {"BLAZE_AMD_GZ_PREFETCH": "0"}),
+                      ("zlib", {"BLAZE_AMD_LIBDEFLATE": "0"})):
+        for k in ("BLAZE_AMD_GZ_PREFETCH_MB", "BLAZE_AMD_GZ_PREFETCH", "BLAZE_AMD_LIBDEFLATE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

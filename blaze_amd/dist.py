@@ -389,6 +389,8 @@ def assign_read_sharded(comm, fastq_fns, fastq_out, putative_bc_csv, whitelsit_c
     spans = partition_files([os.path.getsize(f) for f in fastq_fns], comm.world)
     lo, hi = spans[comm.rank]
     part = part_path(fastq_out, comm.rank)
+    if hi <= lo and os.path.exists(part):
+        os.remove(part)                              # left behind by an earlier run that died: not this run's bytes
     if run_rank is None:
         run_rank = native_run_rank(putative_bc_csv, whitelsit_csv, max_ed, n_process, batchsize, restrand, device)
     # Where do this rank's rows of the table start?  First choice: find the row of its first read in the table itself (no
@@ -502,6 +504,8 @@ def putative_bc_files_sharded(comm, fastq_fns, out_csv, kit, umi_len, min_q, bat
     fastq_fns = [str(f) for f in fastq_fns]
     lo, hi = partition_files([os.path.getsize(f) for f in fastq_fns], comm.world)[comm.rank]
     part = part_path(out_csv, comm.rank)
+    if os.path.exists(part):
+        os.remove(part)                              # an earlier run's: the stage-1 writer creates the table only when it has reads
     if run_rank is None:
         def run_rank(fns, out):
             eng = ra.get_engine(device if device is not None else ra._device_ids(None)[0])

@@ -353,3 +353,44 @@ def test_locate_first_row_of_a_ranks_files(tmp_path):
     assert dist.locate_first_row(str(tmp_path / "t.csv.gz"), fns, 1, 2) is None   # not seekable: the caller counts instead
     (tmp_path / "other.fastq").write_text("@nobody\nA\n+\nI\n")
     assert dist.locate_first_row(str(csv), [str(tmp_path / "other.fastq")], 0, 1) is None
+
+
+def test_sharded_runs_ignore_parts_left_by_a_dead_run(tmp_path):
+    """A rank with no file of its own must not contribute a `.partNNNN` file that an earlier, crashed run left behind
+    (step 3 and the stage-1 table)."""
+    import threading
+    from blaze_amd import dist
+    fq = tmp_path / "only.fastq"
+    fq.write_text("@r0\nACGT\n+\nIIII\n")
+    world = 3
+    for out_name, sharded in (("out.fastq", "step3"), ("putative_bc.csv", "stage1")):
+        out = str(tmp_path / out_name)
+        for r in range(world):
+            with open(dist.part_path(out, r), "wb") as f:
+                f.write(b"STALE BYTES OF A DEAD RUN\n")
+        shared = {"bar": threading.Barrier(world), "lock": threading.Lock()}
+        res = {}
+
+        def rank_main(r):
+            comm = _ThreadComm(r, world, shared)
+            if sharded == "step3":
+                def run_rank(fns, part, skip):
+                    with open(part, "wb") as f:
+                        f.write(b"fresh\n")
+                    return 1, 1
+                res[r] = dist.assign_read_sharded(comm, [str(fq)], out, "unused.csv", "unused", 2, 1, 1000,
+                                                  count_reads=lambda p: 1, run_rank=run_rank)
+            else:
+                def run_rank(fns, part):
+                    with open(part, "wb") as f:
+                        f.write(b"header\nfresh\n")
+                    return {0: 1}
+                res[r] = dist.putative_bc_files_sharded(comm, [str(fq)], out, "3v3", 12, 15, 1000, 1, run_rank=run_rank)
+        ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(60)
+        assert len(res) == world
+        assert open(out, "rb").read() == (b"fresh\n" if sharded == "step3" else b"header\nfresh\n")
+        assert not [f for f in os.listdir(tmp_path) if ".part" in f]

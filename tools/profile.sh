@@ -7,7 +7,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-two-slots --no-files"
+ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-two-slots --no-high-error --no-files"
 pass() {  # name, rocprofv3 options...
     local name=$1; shift
     timeout -s KILL 300 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- python3 $ARGS > "$OUT/$name.json" 2> "$OUT/$name.err" \

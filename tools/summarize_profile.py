@@ -27,7 +27,7 @@ def short(name):
 
 
 print(f"# rocprofv3 summary ({out})\n")
-print("Command of every pass: `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-two-slots --no-files` (1M rows x 5,000 cells).\n")
+print("Command of every pass: `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-two-slots --no-high-error --no-files` (1M rows x 5,000 cells).\n")
 print("## kernel stats (--kernel-trace --stats)\n")
 print("| kernel | calls | total ms | avg us | min us | max us | % |")
 print("|---|---|---|---|---|---|---|")

@@ -334,3 +334,29 @@ def test_many_gzipped_inputs_prefetch_pool(tmp_path, monkeypatch):
                                                batch_size=250, n_threads=8)
         assert sum(counts.values()) == n
     assert (tmp_path / "pool.csv").read_bytes() == (tmp_path / "stream.csv").read_bytes() == (tmp_path / "tight.csv").read_bytes()
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_two_engines_in_one_process_alternate_chunks(tmp_path, gz):
+    """assign_read(devices=[0..7]) in ONE process hands the device batches to the engines round-robin, two slots each
+    (bz_assign_files with n_engines > 1).  The box has one GPU: two engine handles on it stand for two devices; the bytes
+    and counts are those of the one-engine run, whatever the chunk size."""
+    from blaze_amd.engine import Engine
+    n = 5000
+    fns, pc, pw, _ = _make_files(tmp_path, n, 300, seed=131, n_files=4)
+    suffix = ".fastq.gz" if gz else ".fastq"
+    one = str(tmp_path / ("one" + suffix))
+    want = ra.assign_read(fastq_fns=fns, fastq_out=one, putative_bc_csv=pc, whitelsit_csv=pw, max_ed=2, n_process=8, batchsize=200,
+                          restrand=True, host="native")
+    e0 = ra.get_engine(0)
+    ordered = ra._uploaded[0]                      # the order the one-engine run iterated (list(set(...)) of this process)
+    e1 = Engine(0, ra.TIE_RULE)
+    try:
+        e1.set_whitelist(ordered)
+        for rows_per_chunk in (400, 1 << 16):
+            two = str(tmp_path / (f"two_{rows_per_chunk}" + suffix))
+            got = ra._assign_files_native([e0, e1], fns, pc, two, gz, True, 2, 200, rows_per_chunk, 8)
+            assert tuple(map(int, got)) == tuple(map(int, want))
+            assert _text(two) == _text(one)
+    finally:
+        e1.close()

@@ -3,7 +3,7 @@ number of seconds.  Every case draws its own whitelist (with FAMILIES of near-id
 order-dependent fold are the rule, not the exception), rows, error rates, irregular rows / entries, max_ed, tie rule,
 shortcut, scan mode and row stride.  Bit-exact on hit / ed / end / flags or the case is saved and the exit code is 1.
 
-usage: python tools/fuzz_parity.py [seconds] [first_seed]      (test infrastructure: uses oracle/ as the checker)
+usage: python tools/fuzz_parity.py [seconds] [first_seed] [--big]      (test infrastructure: uses oracle/ as the checker)
 """
 import json
 import os
@@ -53,12 +53,19 @@ def draw_whitelist(rng, n_cells, family_frac):
     return [out[k] for k in order]
 
 
-def draw_case(rng):
+def draw_case(rng, big=False):
+    """big: one case in eight takes a whitelist of 46,000 ... 70,000 entries (the streaming pair-seeded kernel instead of
+    the two-kernel path) with a few hundred rows."""
     n_cells = int(rng.choice([1, 2, 3, 5, 31, 63, 64, 65, 127, 200, 257, 777, 1024, 2048, 3001]))
+    large = big and rng.random() < 0.125
+    if large:
+        n_cells = int(rng.integers(46_000, 70_000))
     family = float(rng.choice([0.0, 0.2, 0.6]))
     wl = draw_whitelist(rng, n_cells, family)
     err = float(rng.choice([0.5, 1.0, 3.0, 6.0]))
     n_rows = int(rng.choice([1, 63, 64, 65, 500, 2048, 2500, 4097]))
+    if large:
+        n_rows = min(n_rows, 500)
     # rows: a barcode of the list (or a random 16-mer) with errors, flanks and umi around it
     ext = np.zeros((n_rows, 32), dtype=np.uint8)
     el = np.zeros(n_rows, dtype=np.uint8)
@@ -132,8 +139,10 @@ def draw_case(rng):
 
 
 def main():
-    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    big = "--big" in sys.argv
+    seconds = float(argv[0]) if len(argv) > 0 else 120.0
+    seed0 = int(argv[1]) if len(argv) > 1 else 1
     oracle.build()
     eng = Engine(0)
     os.makedirs("gpurun_out", exist_ok=True)
@@ -144,7 +153,7 @@ def main():
     last_print = time.time()
     while time.time() < t_end:
         rng = np.random.default_rng(seed)
-        p, wl, ext, el, bo, bl = draw_case(rng)
+        p, wl, ext, el, bo, bl = draw_case(rng, big)
         ext_s = np.ascontiguousarray(ext[:, :p["stride"]]) if p["stride"] >= int(el.max(initial=0)) else ext
         if ext_s is ext:
             p["stride"] = 32
@@ -158,7 +167,7 @@ def main():
         bad = np.flatnonzero((hit != o_hit) | (ed != o_ed) | (end != o_end) | ((flags & FLAG_MASK) != o_flag))
         n_cases += 1
         n_rows += ext.shape[0]
-        key = f"ed{p['max_ed']}_m{p['scan_mode']}"
+        key = f"ed{p['max_ed']}_m{p['scan_mode']}" + ("_big" if p["n_cells"] > 40_000 else "")
         stats[key] = stats.get(key, 0) + 1
         if bad.size:
             n_fail += 1

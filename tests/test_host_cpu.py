@@ -146,3 +146,39 @@ def test_gzip_member_crc_matches_zlib_on_edge_lengths():
         assert gzip.decompress(z) == t
         assert int.from_bytes(z[-8:-4], "little") == zlib.crc32(t), n
         assert int.from_bytes(z[-4:], "little") == n
+
+
+def test_gzip_member_sequence_line_trees():
+    """Sequence lines of plain ACGT take one of four fixed trees, sixteen bases per step: every length around the step
+    sizes, each base as the rarest one, ties, lopsided lines (their own tree), one- / two- / three-letter lines, CRLF,
+    a last line without a newline, lines with one foreign byte at every position class -- gzip reads the text back, and
+    balanced lines cost the 2.25 bits per base of the balanced tree."""
+    import gzip
+    import numpy as np
+    from blaze_amd import helper
+    rng = np.random.default_rng(11)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def rec(seq, nl=b"\n"):
+        return b"@r" + nl + seq + nl + b"+" + nl + b"I" * len(seq) + nl
+    for L in list(range(40, 120)) + [255, 256, 257, 1000, 1023, 1024, 1025, 4099]:
+        seq = acgt[rng.integers(0, 4, L)].tobytes()
+        t = rec(seq) * 3
+        assert gzip.decompress(helper.gzip_fastq_member(t)) == t, L
+    for rare in range(4):                                   # which base is the rare one (and exact ties between the others)
+        p = np.full(4, 0.3); p[rare] = 0.1
+        seq = acgt[rng.choice(4, 900, p=p)].tobytes()
+        t = rec(seq) + rec(bytes(acgt[[rare, (rare + 1) % 4, (rare + 2) % 4, (rare + 3) % 4] * 50]))
+        assert gzip.decompress(helper.gzip_fastq_member(t)) == t
+    odd = [b"A" * 500, b"AC" * 300, b"ACG" * 200, b"A" * 400 + b"CGT" * 20, b"ACGT" * 100 + b"N", b"N" + b"ACGT" * 100,
+           b"ACGT" * 50 + b"a" + b"ACGT" * 50, b"ACGT" * 20 + b"\0" + b"ACGT" * 20, bytes(acgt[rng.integers(0, 4, 64)]) + b"\r"]
+    for seq in odd:
+        for nl in (b"\n", b"\r\n"):
+            t = rec(seq, nl) + rec(b"ACGT" * 30, nl)
+            assert gzip.decompress(helper.gzip_fastq_member(t)) == t, seq[:20]
+            assert gzip.decompress(helper.gzip_fastq_member(t[:-len(nl)])) == t[:-len(nl)]
+    t = b"@r\n" + acgt[rng.integers(0, 4, 5000)].tobytes()   # the sequence line is the last line and has no newline
+    assert gzip.decompress(helper.gzip_fastq_member(t)) == t
+    seq = acgt[rng.integers(0, 4, 100_000)].tobytes()
+    z = helper.gzip_fastq_member(b"@r\n" + seq + b"\n+\n")
+    assert len(z) * 8 < 2.26 * len(seq) + 1000

@@ -1362,6 +1362,11 @@ static int assign_files_impl(bz_handle *engines, int n_engines, const char *cons
     job.csv = putative_bc_csv; job.out_path = fastq_out;
     job.gz = gz != 0; job.restrand = restrand != 0; job.max_ed = max_ed; job.batch_size = batch_size;
     job.n_threads = n_threads; job.device_batch_rows = std::min<int64_t>(device_batch_rows, (int64_t)1 << 24);
+    {   // a chunk's reference batches are the tasks of the host threads: a chunk of 66 batches on 16 threads takes five
+        // rounds of which the last is one task; cut chunks at a multiple of (threads x batch) rows where that fits
+        const int64_t round = (int64_t)n_threads * batch_size;
+        if (round <= job.device_batch_rows) job.device_batch_rows = job.device_batch_rows / round * round;
+    }
     job.csv_skip_rows = csv_skip_rows;
     job.csv_byte_offset = csv_byte_offset;
     // How the `.gz` members are compressed.  The reference's gzip.compress is zlib level 9; the decompressed stream is the
@@ -1548,6 +1553,10 @@ int bz_putative_bc_files(bz_handle *engines, int n_engines, const char *const *f
     for (int k = 0; k < n_fastq; ++k) job.fastq_fns.emplace_back(fastq_fns[k]);
     job.out_path = out_csv; job.kit5 = kit_5prime != 0; job.umi_len = umi_len; job.min_q = min_q; job.batch_size = batch_size;
     job.n_threads = n_threads; job.device_batch_reads = std::min<int64_t>(device_batch_reads, (int64_t)1 << 22);
+    {   // whole rounds of (threads x batch) reads per chunk, as in bz_assign_files
+        const int64_t round = (int64_t)n_threads * batch_size;
+        if (round <= job.device_batch_reads) job.device_batch_reads = job.device_batch_reads / round * round;
+    }
 
     struct Queue {                                   // reader thread -> main thread, depth 2
         std::mutex mu; std::condition_variable cv;

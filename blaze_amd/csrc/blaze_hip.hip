@@ -1371,7 +1371,7 @@ static int assign_files_impl(bz_handle *engines, int n_engines, const char *cons
     job.csv_byte_offset = csv_byte_offset;
     // How the `.gz` members are compressed.  The reference's gzip.compress is zlib level 9; the decompressed stream is the
     // contract (the compressed bytes carry a wall-clock mtime and are never reproducible).  Default 0 = the
-    // FASTQ-aware block encoder of fastq_deflate.h (1.8 % larger than level 9, ~30x faster per host thread); 1..9 = zlib
+    // FASTQ-aware block encoder of fastq_deflate.h (1.8 % larger than level 9, ~80x faster per host thread); 1..9 = zlib
     // at that level (BZ_OPT_GZ_LEVEL / BLAZE_AMD_GZ_LEVEL=9 give the reference's setting back).
     job.gz_level = engines[0]->gz_level;
     if (const char *lv = getenv("BLAZE_AMD_GZ_LEVEL")) {

@@ -276,7 +276,7 @@ def assign_read(fastq_fns=None, fastq_out=None, putative_bc_csv=None,
     host="native" (default) runs the batch loop in C++ (bz_assign_files); host="python" runs the
     pandas mirror of the reference's loop below.  Both give the same bytes (of a `.gz` output: the same DECOMPRESSED
     bytes; the native host writes its members with a FASTQ-aware deflate encoder, `gz_level` 1..9 selects zlib at that
-    level instead -- the reference's level 9 makes files 1.8 % smaller at ~30x the CPU time, see INTEGRATION.md section 5;
+    level instead -- the reference's level 9 makes files 1.8 % smaller at ~80x the CPU time, see INTEGRATION.md section 5;
     $BLAZE_AMD_GZ_LEVEL overrides both).
     Returns (reads assigned, reads seen)."""
     if args:

@@ -229,7 +229,7 @@ def main():
                     help="skip the overlapped two-slot leg (tools/profile.sh: keeps every traced launch solo)")
     ap.add_argument("--no-high-error", action="store_true", help="skip the leg with SURVEY 8d's high-error reads")
     ap.add_argument("--no-files", action="store_true", help="skip the step-3-over-files leg (N=1 only)")
-    ap.add_argument("--file-reads", type=int, default=200_000)
+    ap.add_argument("--file-reads", type=int, default=500_000)
     a = ap.parse_args()
     if a.gpus < 1:
         ap.error("--gpus must be >= 1")

@@ -1408,6 +1408,8 @@ static int assign_files_impl(bz_handle *engines, int n_engines, const char *cons
         inflight.clear();
         if (fo) { fclose(fo); fo = nullptr; }
     };
+    bzio::Pool pool(n_threads);                      // the job's host threads (parse, format): alive until the job ends
+    bzio::PoolScope pool_scope(&pool);
     try {
         fo = fopen(fastq_out, "wb");
         if (!fo) throw std::runtime_error(std::string("cannot open ") + fastq_out + " for writing");
@@ -1587,6 +1589,8 @@ int bz_putative_bc_files(bz_handle *engines, int n_engines, const char *const *f
         inflight.clear();
         if (fo) { fclose(fo); fo = nullptr; }
     };
+    bzio::Pool pool(n_threads);                      // the job's host threads (prepare, pack, format): alive until the job ends
+    bzio::PoolScope pool_scope(&pool);
     try {
         reader = std::thread([&]() {
             try {

@@ -584,9 +584,89 @@ struct Job {
 
 struct MismatchError : std::runtime_error { using std::runtime_error::runtime_error; };
 
+// ---- the host threads of one file job ---------------------------------------------------------------------------
+// A job runs a few dozen fork-join loops (parse, format, pack) per second.  Threads that live as long as the job keep
+// their thread_local buffers (the formatter's text, the member encoder's scratch) from one loop to the next and cost no
+// creation; threads made per loop paid for both every time.  The caller of run() works too: n_threads - 1 workers.
+class Pool {
+   public:
+    explicit Pool(int n_threads) {
+        for (int t = 1; t < std::max(1, n_threads); ++t) workers_.emplace_back([this] { work(); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    int size() const { return (int)workers_.size() + 1; }
+    // fn(i) for every i in [0, n_items), items handed out one at a time; returns when all are done; the first exception is rethrown
+    void run(int n_items, const std::function<void(int)> &fn) {
+        if (n_items <= 0) return;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            fn_ = &fn; n_items_ = n_items; next_.store(0); err_ = nullptr;
+            busy_ = (int)workers_.size();
+            ++generation_;
+        }
+        cv_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return busy_ == 0; });
+        fn_ = nullptr;
+        if (err_) std::rethrow_exception(err_);
+    }
+   private:
+    void drain() {
+        try {
+            for (int i; (i = next_.fetch_add(1)) < n_items_;) (*fn_)(i);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(mu_);
+            if (!err_) err_ = std::current_exception();
+            next_.store(n_items_);
+        }
+    }
+    void work() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+            }
+            drain();
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                --busy_;
+            }
+            done_.notify_all();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)> *fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_items_ = 0, busy_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+    std::exception_ptr err_;
+};
+
+// the pool of the job this thread drives (set for the lifetime of a PoolScope); parallel_for uses it when it has the asked size
+inline Pool *&current_pool() { static thread_local Pool *p = nullptr; return p; }
+struct PoolScope {
+    explicit PoolScope(Pool *p) : prev_(current_pool()) { current_pool() = p; }
+    ~PoolScope() { current_pool() = prev_; }
+    Pool *prev_;
+};
+
 template <class F>
 void parallel_for(int n_items, int n_threads, F &&fn) {
     if (n_items <= 0) return;
+    if (Pool *pool = current_pool()) {
+        if (pool->size() == std::max(1, n_threads)) { pool->run(n_items, std::function<void(int)>(std::ref(fn))); return; }
+    }
     const int nt = std::max(1, std::min(n_threads, n_items));
     std::atomic<int> next{0};
     std::exception_ptr err;
@@ -803,7 +883,12 @@ inline void py_cut(uint32_t n, double polyT, uint32_t &start, uint32_t &len) {
 // ---- format one reference batch (read_assignment.py:87-99 epilogue + :214-247) ---------------------------------
 inline void format_batch(Chunk &ch, int b, const Job &job, const std::vector<char> &wl_bytes, const std::vector<int64_t> &wl_off) {
     const uint32_t lo = ch.batch_start[b], hi = ch.batch_start[b + 1];
-    std::string text;
+    // .gz: the text only lives until it is compressed -- one buffer per host thread, grown once; plain: the text IS the
+    // output and is handed to the writer
+    static thread_local std::string tl_text;
+    std::string own;
+    std::string &text = job.gz ? tl_text : own;
+    text.clear();
     {
         size_t bound = 0;                                    // the batch's records at most: no regrowth while appending
         for (uint32_t r = lo; r < hi; ++r)

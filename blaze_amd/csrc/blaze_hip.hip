@@ -468,7 +468,14 @@ int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed
                         else launch_pair_stream(h, s);
                     } else if (seeded) launch_scan_seeded<2>(h, s);
                     else if (filtered) launch_scan_filtered<2>(h, s); else launch_scan<2>(h, s); break;
-            default: if (seeded) launch_scan_seeded<3>(h, s); else launch_scan<3>(h, s); break;
+            case 3: if (seeded) launch_scan_seeded<3>(h, s); else launch_scan<3>(h, s); break;
+            // above 3 no seed plan is exact any more (a 16-mer has no piece that survives 4 edits): every pair through the
+            // packed automaton, 40 (1 + K) instructions per pair
+            case 4: launch_scan<4>(h, s); break;
+            case 5: launch_scan<5>(h, s); break;
+            case 6: launch_scan<6>(h, s); break;
+            case 7: launch_scan<7>(h, s); break;
+            default: launch_scan<8>(h, s); break;
         }
         HIP_TRY(hipGetLastError());
     }
@@ -479,7 +486,12 @@ int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed
             case 0: launch_mixed<0>(h, s); break;
             case 1: launch_mixed<1>(h, s); break;
             case 2: launch_mixed<2>(h, s); break;
-            default: launch_mixed<3>(h, s); break;
+            case 3: launch_mixed<3>(h, s); break;
+            case 4: launch_mixed<4>(h, s); break;
+            case 5: launch_mixed<5>(h, s); break;
+            case 6: launch_mixed<6>(h, s); break;
+            case 7: launch_mixed<7>(h, s); break;
+            default: launch_mixed<8>(h, s); break;
         }
         HIP_TRY(hipGetLastError());
     }
@@ -634,7 +646,7 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
     const int64_t nf = (int64_t)reg_pos.size();
     // (an empty entry is a falsy hit in the reference's fold and event words hold the index in 25 bits: such lists take
     // the byte-wise scan as a whole when they are not all regular)
-    const bool regular = nf > 0 && (nf == n || (n - nf <= kMaxIrregular && !empty_entry && n < ((int64_t)1 << 25)));
+    const bool regular = nf > 0 && (nf == n || (n - nf <= kMaxIrregular && !empty_entry && n < ((int64_t)1 << 23)));   // k_fix_rows' event words: 23 bits of index at max_ed > 3
     const bool mixed = regular && nf < n;
     // byte form (generic kernel + histogram size)
     std::vector<int64_t> off(n + 1);

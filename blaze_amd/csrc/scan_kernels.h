@@ -33,7 +33,7 @@ namespace bz {
 
 constexpr int kBcLen = 16;        // config.py:34
 constexpr int kTextCols = 20;     // 2 + 16 + 2 (config.py:75, read_assignment.py:70)
-constexpr int kMaxK = 3;          // bit-parallel kernels are instantiated for max_ed 0..3
+constexpr int kMaxK = 8;          // the packed automaton is instantiated for max_ed 0..8 (seeded forms: 0..3, all pairs above)
 constexpr uint32_t kOne2 = 0x00010001u;
 constexpr int kHitNone = -1;
 constexpr int kHitAmbiguous = -2;
@@ -1598,6 +1598,7 @@ __global__ __launch_bounds__(256) void k_fix_rows(
     const int32_t *__restrict__ fix_list, const int32_t *__restrict__ n_fix_ptr, int tie,
     int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
     __shared__ uint32_t s_min[2][K + 1];
+    constexpr int kEdBits = K <= 3 ? 2 : 4;                       // event word: index | ed | end (5 bits); 25 / 23 bits of index (host checks)
     const int n_fix = *n_fix_ptr;
     const int tid = threadIdx.x;
     for (int f = blockIdx.x; f < n_fix; f += gridDim.x) {         // workgroup-uniform
@@ -1617,7 +1618,7 @@ __global__ __launch_bounds__(256) void k_fix_rows(
 #pragma unroll
         for (int c = 0; c <= K; ++c) { keep[c][0] = 0xFFFFFFFFu; keep[c][1] = 0xFFFFFFFFu; }
         auto note = [&](int idx, int ed, int end) {
-            const uint32_t ev = ((uint32_t)idx << 7) | ((uint32_t)ed << 5) | (uint32_t)(end < 0 ? kEndNone : end);
+            const uint32_t ev = ((uint32_t)idx << (5 + kEdBits)) | ((uint32_t)ed << 5) | (uint32_t)(end < 0 ? kEndNone : end);
 #pragma unroll
             for (int c = 0; c <= K; ++c) {
                 if (c != ed) continue;
@@ -1666,7 +1667,7 @@ __global__ __launch_bounds__(256) void k_fix_rows(
             bool done = false;
             for (int a = 0; a < nev; ++a) {
                 const int e = (int)(ev[a] & 31u);
-                fold_update((int)((ev[a] >> 5) & 3u), e == kEndNone ? -1 : e, (int)(ev[a] >> 7), best, hit, hit_end, done);
+                fold_update((int)((ev[a] >> 5) & ((1u << kEdBits) - 1u)), e == kEndNone ? -1 : e, (int)(ev[a] >> (5 + kEdBits)), best, hit, hit_end, done);
             }
             hit_out[r] = hit >= 0 ? hit : -1;
             ed_out[r] = (int8_t)best;

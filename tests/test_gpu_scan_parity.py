@@ -182,18 +182,27 @@ def test_irregular_rows_every_kind(engine, oracle, max_ed, tie, mixed):
     assert ((flags & _lib.BZ_F_EXACT) != 0)[np.arange(n) % 12 == 8].sum() > 50
 
 
-@pytest.mark.parametrize("max_ed", [4, 5, 8, 9])
-def test_max_ed_above_the_packed_kernels(engine, oracle, max_ed):
-    """--max-edit-distance above 3: no row takes the packed kernels; 4..8 go through the workgroup-per-row scan, 9 through
-    the one-lane byte-wise scan.  Near matches are everywhere at these cut-offs, so the fold's tie cascade is exercised."""
+@pytest.mark.parametrize("max_ed", [4, 5, 6, 7, 8, 9])
+def test_max_ed_above_the_seeded_kernels(engine, oracle, max_ed):
+    """--max-edit-distance above 3: no seed plan is exact any more; regular rows take the packed automaton over every pair
+    up to 8 (irregular rows the workgroup-per-row scan), 9 and above the one-lane byte-wise scan.  Near matches are
+    everywhere at these cut-offs, so the fold's tie cascade is exercised."""
     rows, wl = _synthetic(700, 120, err=4.0, seed=95)
     ext, el, bo, bl = synth.pack_ext(rows)
     ext[5, 3] = ord("N")
     for tie in (0, 1):
         hit, ed, end, flags = _compare(engine, oracle, ext, el, bo, bl, [w.tobytes() for w in wl], max_ed, tie)
     t = engine.timing(0)
-    assert t["rows_bitparallel"] == 0 and t["rows_generic"] > 400
+    if max_ed <= 8:
+        assert t["rows_bitparallel"] > 400 and 1 <= t["rows_generic"] < 20
+    else:
+        assert t["rows_bitparallel"] == 0 and t["rows_generic"] > 400
     assert ((hit >= 0) & ((flags & _lib.BZ_F_EXACT) == 0)).sum() > 50
+    # a mixed whitelist at these cut-offs: the irregular entries are within reach of most rows, every such row is re-scored
+    wl_list = [w.tobytes() for w in wl]
+    wl_list.insert(7, wl_list[3][:15])
+    wl_list.append(wl_list[9][:6] + b"N" + wl_list[9][7:])
+    _compare(engine, oracle, ext, el, bo, bl, wl_list, max_ed, 0)
 
 
 @pytest.mark.parametrize("scan_mode", **MODES)

@@ -131,7 +131,7 @@ def draw_case(rng, big=False):
                 wl[wl.index(base)] = new                           # replaces its parent
             else:
                 wl.insert(pos, new)
-    max_ed = int(rng.choice([0, 1, 2, 2, 2, 3, 3, 4, 5]))
+    max_ed = int(rng.choice([0, 1, 2, 2, 2, 3, 3, 4, 5, 6, 7, 8]))
     params = dict(n_cells=len(wl), family=family, err=err, n_rows=n_rows, irregular_rows=bool(irregular_rows), mixed=bool(mixed),
                   max_ed=max_ed, tie=int(rng.integers(0, 2)), shortcut=bool(rng.random() < 0.8),
                   scan_mode=int(rng.choice([0, 0, 1, 2, 3, 4])), stride=int(rng.choice([20, 24, 32])))

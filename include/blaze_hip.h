@@ -52,7 +52,8 @@ typedef struct bz_engine *bz_handle;
 #define BZ_OPT_FORCE_GENERIC 3 /* 1 = send every row through the byte-wise DP kernel (testing) */
 #define BZ_OPT_SCAN_MODE 4     /* 0 (default) = pigeonhole seeds + verify for max_ed <= 3 (max_ed 2: two untouched
                                   4-nt pieces of four; max_ed <= 1: one untouched 8-nt piece of two; max_ed 3: one
-                                  untouched 4-nt piece of four), byte-wise scan above; 1 = brute force always: every (row, barcode) pair runs the automaton
+                                  untouched 4-nt piece of four), every pair through the packed automaton for max_ed 4..8, byte-wise scan above;
+                                  1 = brute force always: every (row, barcode) pair runs the automaton
                                   (the roofline leg of bench.py); 2 = exact 3-gram filter + verify over the
                                   whole whitelist (also finishes the rows mode 0 hands on); 3 = single-piece
                                   seeds 5|5|6 for max_ed 2 (the first seeded scan, kept for comparison).

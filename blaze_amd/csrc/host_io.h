@@ -298,7 +298,7 @@ class FastqFiles {
                     bool room;
                     { std::lock_guard<std::mutex> g(state_->mu); room = state_->bytes < budget_; }
                     if (k <= next_needed_ || (k < next_needed_ + ahead_ && room)) break;
-                    cv_.wait_for(lk, std::chrono::milliseconds(20));
+                    cv_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(20));   // (system clock: pthread_cond_timedwait, which ThreadSanitizer understands)
                 }
                 slots_[k].started = true;
                 scan_ = k + 1;

@@ -182,3 +182,23 @@ def test_gzip_member_sequence_line_trees():
     seq = acgt[rng.integers(0, 4, 100_000)].tobytes()
     z = helper.gzip_fastq_member(b"@r\n" + seq + b"\n+\n")
     assert len(z) * 8 < 2.26 * len(seq) + 1000
+
+
+def test_host_threading_under_thread_sanitizer(tmp_path):
+    """tools/host_tsan.cpp (the job-long thread pool, the member encoder's per-thread buffers, the pool that inflates
+    gzipped inputs ahead of the reader) built with -fsanitize=thread: no report.  Host code only."""
+    import shutil
+    import subprocess
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_tsan")
+    if shutil.which("g++") is None or shutil.which("gzip") is None:
+        pytest.skip("needs g++ and gzip")
+    b = subprocess.run(["g++", "-O1", "-g", "-fsanitize=thread", "-std=c++17", "-pthread", "-w", os.path.join(root, "tools", "host_tsan.cpp"),
+                        "-lz", "-ldl", "-o", exe], capture_output=True, text=True)
+    if b.returncode != 0 and "tsan" in b.stderr.lower():
+        pytest.skip("no ThreadSanitizer runtime on this host")
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([exe, str(tmp_path / "fq")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert "lines 65000" in r.stdout and "caught 50" in r.stdout

@@ -53,6 +53,10 @@ inline bool py_space(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13) |
 class Arena {
    public:
     char *alloc(size_t n) {
+#ifdef BZ_ARENA_EXACT                                  // sanitizer builds (tools/host_asan.cpp): every line its own heap block, so a byte read past it is seen
+        blocks_.emplace_back(new char[std::max<size_t>(n, 1)]);
+        return blocks_.back().get();
+#endif
         if (n > room_) {
             const size_t sz = std::max<size_t>(n, (size_t)4 << 20);
             blocks_.emplace_back(new char[sz]);
@@ -62,7 +66,13 @@ class Arena {
         cur_ += n; room_ -= n;
         return p;
     }
-    void give_back(size_t n) { cur_ -= n; room_ += n; }          // undo the tail of the last alloc
+    void give_back(size_t n) {                                   // undo the tail of the last alloc
+#ifdef BZ_ARENA_EXACT
+        (void)n;
+        return;
+#endif
+        cur_ -= n; room_ += n;
+    }
    private:
     std::vector<std::unique_ptr<char[]>> blocks_;
     char *cur_ = nullptr;

@@ -202,3 +202,26 @@ def test_host_threading_under_thread_sanitizer(tmp_path):
     r = subprocess.run([exe, str(tmp_path / "fq")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
     assert "lines 65000" in r.stdout and "caught 50" in r.stdout
+
+
+def test_host_parse_and_format_under_address_sanitizer(tmp_path):
+    """tools/host_asan.cpp: the lock-step reader, parse_batch, format_batch and the stage-1 host side on quirky inputs
+    with made-up device results, built with -fsanitize=address,undefined and every copied line in a heap block of its
+    own (BZ_ARENA_EXACT): no report, with the streaming gz reader and with the prefetch pool.  Host code only."""
+    import shutil
+    import subprocess
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_asan")
+    if shutil.which("g++") is None or shutil.which("gzip") is None:
+        pytest.skip("needs g++ and gzip")
+    b = subprocess.run(["g++", "-O1", "-g", "-DBZ_ARENA_EXACT", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-std=c++17",
+                        "-pthread", "-w", os.path.join(root, "tools", "host_asan.cpp"), "-lz", "-ldl", "-o", exe], capture_output=True, text=True)
+    if b.returncode != 0 and "asan" in b.stderr.lower():
+        pytest.skip("no AddressSanitizer runtime on this host")
+    assert b.returncode == 0, b.stderr[-2000:]
+    for prefetch in ("0", "1"):
+        env = dict(os.environ, BLAZE_AMD_GZ_PREFETCH=prefetch)
+        r = subprocess.run([exe, str(tmp_path / f"d{prefetch}")], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+        assert "bytes formatted" in r.stdout

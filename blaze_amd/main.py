@@ -112,7 +112,10 @@ def count_high_quality_bc(args):
     reference's own insertion order (it decides the order of whitelist.csv and of the empty-drop candidates)."""
     raw_bc_count = Counter()
     for df in _count_chunks(args.out_raw_bc_fn):
-        raw_bc_count += Counter(df[df.putative_bc_min_q >= args.minQ].putative_bc.value_counts().to_dict())
+        # the reference's `raw_bc_count += Counter(d)` (main.py:381-382): counts added, new keys appended in d's order, and
+        # nothing to drop (value_counts gives counts >= 1) -- which is Counter.update(d), a C-level dict.update for the
+        # first chunk instead of a Python loop over every barcode and a second pass that looks for non-positive counts
+        raw_bc_count.update(df[df.putative_bc_min_q >= args.minQ].putative_bc.value_counts().to_dict())
     return raw_bc_count
 
 

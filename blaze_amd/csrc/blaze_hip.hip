@@ -1391,165 +1391,66 @@ static int assign_files_impl(bz_handle *engines, int n_engines, const char *cons
         if (v >= 0 && v <= 9 && (v > 0 || lv[0] == '0')) job.gz_level = v;
     }
 
-    struct Queue {                                   // reader thread -> main thread, depth 2
-        std::mutex mu; std::condition_variable cv;
-        std::deque<std::unique_ptr<bzio::Chunk>> q;
-        bool done = false, stop = false;
-        std::exception_ptr err;
-    } Q;
-    struct WQueue {                                  // main thread -> writer thread, in order, depth 4
-        std::mutex mu; std::condition_variable cv;
-        std::deque<std::vector<std::string>> q;
-        bool done = false, failed = false;
-    } W;
-    std::thread reader, writer;
-    std::deque<std::unique_ptr<bzio::Chunk>> inflight;
-    FILE *fo = nullptr;
-    int64_t demul_tot = 0, reads_tot = 0, n_chunks = 0;
+    int64_t demul_tot = 0, reads_tot = 0;
     int rc = BZ_OK;
     bzio::StageClock clk;                            // 0 reader, 1 wait for reader, 2 parse, 3 submit, 4 wait device, 5 format, 6 hand to writer, 7 write
     const double t_job = bzio::StageClock::now();
-    auto shutdown = [&]() {
-        { std::lock_guard<std::mutex> g(Q.mu); Q.stop = true; }
-        Q.cv.notify_all();
-        if (reader.joinable()) reader.join();
-        { std::lock_guard<std::mutex> g(W.mu); W.done = true; }
-        W.cv.notify_all();
-        if (writer.joinable()) writer.join();
-        for (auto &c : inflight) hipStreamSynchronize(engines[c->engine]->slot[c->slot].stream);
-        inflight.clear();
-        if (fo) { fclose(fo); fo = nullptr; }
-    };
     bzio::Pool pool(n_threads);                      // the job's host threads (parse, format): alive until the job ends
     bzio::PoolScope pool_scope(&pool);
+    const bz_handle e0 = engines[0];
+    bzio::OrderedPipeline<bzio::Chunk> pipe;
+    pipe.out_path = fastq_out;
+    pipe.create_output_first = true;                 // the reference opens its output before the first batch (read_assignment.py:279-283)
+    pipe.max_inflight = 2 * n_engines;
+    pipe.clk = &clk;
+    pipe.open_reader = [&]() {
+        auto rd = std::make_shared<bzio::ChunkReader>(job);
+        return std::function<std::unique_ptr<bzio::Chunk>()>([rd]() { return rd->next(); });
+    };
+    pipe.submit = [&](bzio::Chunk &c, int64_t k) {
+        double t1 = bzio::StageClock::now();
+        const size_t n = c.reads.size();
+        c.bc.resize(n); c.umi.resize(n); c.post.resize(n); c.rid.resize(n); c.polyT.resize(n);
+        c.ext.resize(n * bzio::kExtStride); c.ext_len.resize(n); c.bc_off.resize(n); c.bc_len.resize(n);
+        bzio::parallel_for((int)c.batch_start.size() - 1, job.n_threads, [&](int b) { bzio::parse_batch(c, b); });
+        const double t2 = bzio::StageClock::now();
+        clk.t[2] += t2 - t1;
+        c.engine = (int)(k % n_engines); c.slot = (int)((k / n_engines) % 2);
+        if (bz_assign_submit(engines[c.engine], c.slot, c.ext.data(), bzio::kExtStride, c.ext_len.data(), c.bc_off.data(),
+                             c.bc_len.data(), (int64_t)n, max_ed) != BZ_OK)
+            throw std::runtime_error(g_err);
+        clk.t[3] += bzio::StageClock::now() - t2;
+    };
+    pipe.finish = [&](bzio::Chunk &c, std::vector<std::string> &parts) {
+        const size_t n = c.reads.size();
+        c.hit.resize(n); c.ed.resize(n); c.end_idx.resize(n); c.flags.resize(n);
+        const double t0 = bzio::StageClock::now();
+        if (bz_assign_wait(engines[c.engine], c.slot, c.hit.data(), c.ed.data(), c.end_idx.data(), c.flags.data()) != BZ_OK)
+            throw std::runtime_error(g_err);
+        const double t1 = bzio::StageClock::now();
+        clk.t[4] += t1 - t0;
+        const int nb = (int)c.batch_start.size() - 1;
+        c.out.resize(nb); c.demul.assign(nb, 0);
+        bzio::parallel_for(nb, job.n_threads, [&](int b) { bzio::format_batch(c, b, job, e0->wl_host, e0->wl_off_host); });
+        clk.t[5] += bzio::StageClock::now() - t1;
+        for (int b = 0; b < nb; ++b) demul_tot += c.demul[b];
+        reads_tot += (int64_t)n;
+        parts = std::move(c.out);
+    };
+    pipe.abandon = [&](bzio::Chunk &c) { hipStreamSynchronize(engines[c.engine]->slot[c.slot].stream); };
     try {
-        fo = fopen(fastq_out, "wb");
-        if (!fo) throw std::runtime_error(std::string("cannot open ") + fastq_out + " for writing");
-        reader = std::thread([&]() {
-            try {
-                bzio::ChunkReader rd(job);
-                for (;;) {
-                    const double t0 = bzio::StageClock::now();
-                    auto ch = rd.next();
-                    clk.t[0] += bzio::StageClock::now() - t0;
-                    std::unique_lock<std::mutex> lk(Q.mu);
-                    if (!ch) break;
-                    Q.cv.wait(lk, [&] { return Q.q.size() < 2 || Q.stop; });
-                    if (Q.stop) return;
-                    Q.q.push_back(std::move(ch));
-                    Q.cv.notify_all();
-                }
-            } catch (...) {
-                std::lock_guard<std::mutex> g(Q.mu);
-                Q.err = std::current_exception();
-            }
-            { std::lock_guard<std::mutex> g(Q.mu); Q.done = true; }
-            Q.cv.notify_all();
-        });
-        writer = std::thread([&]() {
-            for (;;) {
-                std::vector<std::string> parts;
-                {
-                    std::unique_lock<std::mutex> lk(W.mu);
-                    W.cv.wait(lk, [&] { return !W.q.empty() || W.done; });
-                    if (W.q.empty()) return;
-                    parts = std::move(W.q.front());
-                    W.q.pop_front();
-                }
-                W.cv.notify_all();
-                const double t0 = bzio::StageClock::now();
-                for (const std::string &part : parts)
-                    if (!part.empty() && !W.failed && fwrite(part.data(), 1, part.size(), fo) != part.size()) {
-                        std::lock_guard<std::mutex> g(W.mu);
-                        W.failed = true;
-                    }
-                clk.t[7] += bzio::StageClock::now() - t0;
-            }
-        });
-        const bz_handle e0 = engines[0];
-        auto finish = [&](std::unique_ptr<bzio::Chunk> ch) {
-            const size_t n = ch->reads.size();
-            ch->hit.resize(n); ch->ed.resize(n); ch->end_idx.resize(n); ch->flags.resize(n);
-            double t0 = bzio::StageClock::now();
-            if (bz_assign_wait(engines[ch->engine], ch->slot, ch->hit.data(), ch->ed.data(), ch->end_idx.data(), ch->flags.data()) != BZ_OK)
-                throw std::runtime_error(g_err);
-            double t1 = bzio::StageClock::now();
-            clk.t[4] += t1 - t0;
-            const int nb = (int)ch->batch_start.size() - 1;
-            ch->out.resize(nb); ch->demul.assign(nb, 0);
-            bzio::Chunk &c = *ch;
-            bzio::parallel_for(nb, job.n_threads, [&](int b) { bzio::format_batch(c, b, job, e0->wl_host, e0->wl_off_host); });
-            t0 = bzio::StageClock::now();
-            clk.t[5] += t0 - t1;
-            for (int b = 0; b < nb; ++b) demul_tot += c.demul[b];
-            reads_tot += (int64_t)n;
-            {
-                std::unique_lock<std::mutex> lk(W.mu);
-                W.cv.wait(lk, [&] { return W.q.size() < 4 || W.failed; });
-                if (W.failed) throw std::runtime_error(std::string("write error on ") + fastq_out);
-                W.q.push_back(std::move(c.out));
-            }
-            W.cv.notify_all();
-            clk.t[6] += bzio::StageClock::now() - t0;
-        };
-        for (int64_t k = 0;; ++k) {
-            std::unique_ptr<bzio::Chunk> ch;
-            double t0 = bzio::StageClock::now();
-            {
-                std::unique_lock<std::mutex> lk(Q.mu);
-                Q.cv.wait(lk, [&] { return !Q.q.empty() || Q.done; });
-                if (Q.err) std::rethrow_exception(Q.err);
-                if (Q.q.empty()) break;
-                ch = std::move(Q.q.front());
-                Q.q.pop_front();
-            }
-            Q.cv.notify_all();
-            double t1 = bzio::StageClock::now();
-            clk.t[1] += t1 - t0;
-            const size_t n = ch->reads.size();
-            ch->bc.resize(n); ch->umi.resize(n); ch->post.resize(n); ch->rid.resize(n); ch->polyT.resize(n);
-            ch->ext.resize(n * bzio::kExtStride); ch->ext_len.resize(n); ch->bc_off.resize(n); ch->bc_len.resize(n);
-            bzio::Chunk &c = *ch;
-            bzio::parallel_for((int)c.batch_start.size() - 1, job.n_threads, [&](int b) { bzio::parse_batch(c, b); });
-            clk.t[2] += bzio::StageClock::now() - t1;
-            if ((int)inflight.size() == 2 * n_engines) {
-                auto old = std::move(inflight.front());
-                inflight.pop_front();
-                finish(std::move(old));
-            }
-            t1 = bzio::StageClock::now();
-            c.engine = (int)(k % n_engines); c.slot = (int)((k / n_engines) % 2);
-            if (bz_assign_submit(engines[c.engine], c.slot, c.ext.data(), bzio::kExtStride, c.ext_len.data(), c.bc_off.data(),
-                                 c.bc_len.data(), (int64_t)n, max_ed) != BZ_OK)
-                throw std::runtime_error(g_err);
-            clk.t[3] += bzio::StageClock::now() - t1;
-            inflight.push_back(std::move(ch));
-            ++n_chunks;
-        }
-        while (!inflight.empty()) {
-            auto old = std::move(inflight.front());
-            inflight.pop_front();
-            finish(std::move(old));
-        }
-        { std::lock_guard<std::mutex> g(W.mu); W.done = true; }
-        W.cv.notify_all();
-        writer.join();
-        if (W.failed) throw std::runtime_error(std::string("write error on ") + fastq_out);
-        if (fclose(fo) != 0) { fo = nullptr; throw std::runtime_error(std::string("write error on ") + fastq_out); }
-        fo = nullptr;
+        pipe.run();
     } catch (const bzio::MismatchError &e) {
         rc = fail(BZ_E_MISMATCH, "%s", e.what());
     } catch (const std::exception &e) {
         rc = fail(BZ_E_ARG, "%s", e.what());
     }
+    const int64_t n_chunks = pipe.n_chunks;
     if (getenv("BLAZE_AMD_IO_TIMING"))
         fprintf(stderr, "[bz_assign_files] %.3f s total | reader thread %.3f | main: wait reader %.3f parse %.3f submit %.3f wait device %.3f "
                         "format %.3f hand-over %.3f | writer thread %.3f | %lld reads, %lld chunks, %d threads\n",
                 bzio::StageClock::now() - t_job, clk.t[0], clk.t[1], clk.t[2], clk.t[3], clk.t[4], clk.t[5], clk.t[6], clk.t[7],
                 (long long)reads_tot, (long long)n_chunks, n_threads);
-    const std::string keep = g_err;
-    shutdown();
-    g_err = keep;
     if (out_counts) { out_counts[0] = demul_tot; out_counts[1] = reads_tot; out_counts[2] = n_chunks; out_counts[3] = 0; }
     return rc;
 }
@@ -1572,170 +1473,70 @@ int bz_putative_bc_files(bz_handle *engines, int n_engines, const char *const *f
         if (round <= job.device_batch_reads) job.device_batch_reads = job.device_batch_reads / round * round;
     }
 
-    struct Queue {                                   // reader thread -> main thread, depth 2
-        std::mutex mu; std::condition_variable cv;
-        std::deque<std::unique_ptr<bzio::S1Chunk>> q;
-        bool done = false, stop = false;
-        std::exception_ptr err;
-    } Q;
-    struct WQueue {                                  // main thread -> writer thread, in order, depth 4
-        std::mutex mu; std::condition_variable cv;
-        std::deque<std::vector<std::string>> q;
-        bool done = false, failed = false;
-    } W;
-    std::thread reader, writer;
-    std::deque<std::unique_ptr<bzio::S1Chunk>> inflight;
-    FILE *fo = nullptr;
-    int64_t totals[5] = {0, 0, 0, 0, 0}, reads_tot = 0, n_chunks = 0;
+    int64_t totals[5] = {0, 0, 0, 0, 0}, reads_tot = 0;
     int rc = BZ_OK;
-    bzio::StageClock clk;                            // 0 reader, 1 wait for reader, 2 pack, 4 wait device, 5 format, 6 hand to writer, 7 write
+    bzio::StageClock clk;                            // 0 reader, 1 wait for reader, 2 prepare, 3 pack + submit, 4 wait device, 5 format, 6 hand to writer, 7 write
     const double t_job = bzio::StageClock::now();
-    auto shutdown = [&]() {
-        { std::lock_guard<std::mutex> g(Q.mu); Q.stop = true; }
-        Q.cv.notify_all();
-        if (reader.joinable()) reader.join();
-        { std::lock_guard<std::mutex> g(W.mu); W.done = true; }
-        W.cv.notify_all();
-        if (writer.joinable()) writer.join();
-        for (auto &c : inflight) hipStreamSynchronize(engines[c->engine]->slot[c->slot].stream);
-        inflight.clear();
-        if (fo) { fclose(fo); fo = nullptr; }
-    };
     bzio::Pool pool(n_threads);                      // the job's host threads (prepare, pack, format): alive until the job ends
     bzio::PoolScope pool_scope(&pool);
+    bzio::OrderedPipeline<bzio::S1Chunk> pipe;
+    pipe.out_path = out_csv;
+    pipe.create_output_first = false;                // the reference creates the table with its first batch (main.py:361-362): no reads, no table
+    pipe.max_inflight = BZ_SLOTS * n_engines;
+    pipe.clk = &clk;
+    pipe.open_reader = [&]() {
+        auto rd = std::make_shared<bzio::FastqChunkReader>(job);
+        return std::function<std::unique_ptr<bzio::S1Chunk>()>([rd]() { return rd->next(); });
+    };
+    pipe.submit = [&](bzio::S1Chunk &c, int64_t k) {
+        double t1 = bzio::StageClock::now();
+        c.first = k == 0;
+        c.engine = (int)(k % n_engines); c.slot = (int)((k / n_engines) % BZ_SLOTS);
+        bzio::s1_prepare(c, job.n_threads);
+        const double t2 = bzio::StageClock::now();
+        clk.t[2] += t2 - t1;
+        bz_handle e = engines[c.engine];
+        if (use(e) != BZ_OK) throw std::runtime_error(g_err);
+        const int64_t n = (int64_t)c.reads.size();
+        S1Buf &b = e->s1[c.slot];
+        if (s1_ensure(b, e->slot[c.slot].stream, c.off[n], n) != BZ_OK) throw std::runtime_error(g_err);
+        bzio::s1_copy(c, b.h_seq, b.h_qual, b.h_off, job.n_threads);
+        if (s1_launch(e, c.slot, n, job.kit5 ? 1 : 0, job.umi_len) != BZ_OK) throw std::runtime_error(g_err);
+        clk.t[3] += bzio::StageClock::now() - t2;
+    };
+    pipe.finish = [&](bzio::S1Chunk &c, std::vector<std::string> &parts) {
+        bz_handle e = engines[c.engine];
+        S1Buf &b = e->s1[c.slot];
+        const size_t n = c.reads.size();
+        const double t0 = bzio::StageClock::now();
+        if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->slot[c.slot].stream) != hipSuccess)
+            throw std::runtime_error("device search failed");
+        c.code.assign(b.h_i32, b.h_i32 + n); c.start.assign(b.h_i32 + n, b.h_i32 + 2 * n);
+        c.minq.assign(b.h_i32 + 2 * n, b.h_i32 + 3 * n); c.polyt.assign(b.h_i32 + 3 * n, b.h_i32 + 4 * n);
+        c.strand.assign(b.h_strand, b.h_strand + n);                // the slot's buffers are free again from here
+        const double t1 = bzio::StageClock::now();
+        clk.t[4] += t1 - t0;
+        const int nb = (int)c.batch_start.size() - 1;
+        c.out.resize(nb); c.pass.resize(nb);
+        bzio::parallel_for(nb, job.n_threads, [&](int bi) { bzio::s1_format_batch(c, bi, job); });
+        clk.t[5] += bzio::StageClock::now() - t1;
+        for (int bi = 0; bi < nb; ++bi)
+            for (int k = 0; k < 5; ++k) totals[k] += c.pass[bi][k];
+        reads_tot += (int64_t)n;
+        parts = std::move(c.out);
+    };
+    pipe.abandon = [&](bzio::S1Chunk &c) { hipStreamSynchronize(engines[c.engine]->slot[c.slot].stream); };
     try {
-        reader = std::thread([&]() {
-            try {
-                bzio::FastqChunkReader rd(job);
-                for (;;) {
-                    const double t0 = bzio::StageClock::now();
-                    auto ch = rd.next();
-                    clk.t[0] += bzio::StageClock::now() - t0;
-                    std::unique_lock<std::mutex> lk(Q.mu);
-                    if (!ch) break;
-                    Q.cv.wait(lk, [&] { return Q.q.size() < 2 || Q.stop; });
-                    if (Q.stop) return;
-                    Q.q.push_back(std::move(ch));
-                    Q.cv.notify_all();
-                }
-            } catch (...) {
-                std::lock_guard<std::mutex> g(Q.mu);
-                Q.err = std::current_exception();
-            }
-            { std::lock_guard<std::mutex> g(Q.mu); Q.done = true; }
-            Q.cv.notify_all();
-        });
-        writer = std::thread([&]() {
-            for (;;) {
-                std::vector<std::string> parts;
-                {
-                    std::unique_lock<std::mutex> lk(W.mu);
-                    W.cv.wait(lk, [&] { return !W.q.empty() || W.done; });
-                    if (W.q.empty()) return;
-                    parts = std::move(W.q.front());
-                    W.q.pop_front();
-                }
-                W.cv.notify_all();
-                const double t0 = bzio::StageClock::now();
-                for (const std::string &part : parts)
-                    if (!part.empty() && !W.failed && fwrite(part.data(), 1, part.size(), fo) != part.size()) {
-                        std::lock_guard<std::mutex> g(W.mu);
-                        W.failed = true;
-                    }
-                clk.t[7] += bzio::StageClock::now() - t0;
-            }
-        });
-        auto finish = [&](std::unique_ptr<bzio::S1Chunk> ch) {
-            bzio::S1Chunk &c = *ch;
-            bz_handle e = engines[c.engine];
-            S1Buf &b = e->s1[c.slot];
-            const size_t n = c.reads.size();
-            double t0 = bzio::StageClock::now();
-            if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->slot[c.slot].stream) != hipSuccess)
-                throw std::runtime_error("device search failed");
-            c.code.assign(b.h_i32, b.h_i32 + n); c.start.assign(b.h_i32 + n, b.h_i32 + 2 * n);
-            c.minq.assign(b.h_i32 + 2 * n, b.h_i32 + 3 * n); c.polyt.assign(b.h_i32 + 3 * n, b.h_i32 + 4 * n);
-            c.strand.assign(b.h_strand, b.h_strand + n);                // the slot's buffers are free again from here
-            double t1 = bzio::StageClock::now();
-            clk.t[4] += t1 - t0;
-            const int nb = (int)c.batch_start.size() - 1;
-            c.out.resize(nb); c.pass.resize(nb);
-            bzio::parallel_for(nb, job.n_threads, [&](int bi) { bzio::s1_format_batch(c, bi, job); });
-            t0 = bzio::StageClock::now();
-            clk.t[5] += t0 - t1;
-            for (int bi = 0; bi < nb; ++bi)
-                for (int k = 0; k < 5; ++k) totals[k] += c.pass[bi][k];
-            reads_tot += (int64_t)n;
-            if (!fo) {                                   // the reference creates the table with its first batch (main.py:361-362)
-                fo = fopen(out_csv, "wb");
-                if (!fo) throw std::runtime_error(std::string("cannot open ") + out_csv + " for writing");
-            }
-            {
-                std::unique_lock<std::mutex> lk(W.mu);
-                W.cv.wait(lk, [&] { return W.q.size() < 4 || W.failed; });
-                if (W.failed) throw std::runtime_error(std::string("write error on ") + out_csv);
-                W.q.push_back(std::move(c.out));
-            }
-            W.cv.notify_all();
-            clk.t[6] += bzio::StageClock::now() - t0;
-        };
-        for (int64_t k = 0;; ++k) {
-            std::unique_ptr<bzio::S1Chunk> ch;
-            double t0 = bzio::StageClock::now();
-            {
-                std::unique_lock<std::mutex> lk(Q.mu);
-                Q.cv.wait(lk, [&] { return !Q.q.empty() || Q.done; });
-                if (Q.err) std::rethrow_exception(Q.err);
-                if (Q.q.empty()) break;
-                ch = std::move(Q.q.front());
-                Q.q.pop_front();
-            }
-            Q.cv.notify_all();
-            double t1 = bzio::StageClock::now();
-            clk.t[1] += t1 - t0;
-            ch->first = k == 0;
-            ch->engine = (int)(k % n_engines); ch->slot = (int)((k / n_engines) % BZ_SLOTS);
-            bzio::s1_prepare(*ch, job.n_threads);
-            clk.t[2] += bzio::StageClock::now() - t1;
-            if ((int)inflight.size() == BZ_SLOTS * n_engines) {       // the oldest chunk holds this chunk's staging buffers
-                auto old = std::move(inflight.front());
-                inflight.pop_front();
-                finish(std::move(old));
-            }
-            t1 = bzio::StageClock::now();
-            bz_handle e = engines[ch->engine];
-            if (use(e) != BZ_OK) throw std::runtime_error(g_err);
-            const int64_t n = (int64_t)ch->reads.size();
-            S1Buf &b = e->s1[ch->slot];
-            if (s1_ensure(b, e->slot[ch->slot].stream, ch->off[n], n) != BZ_OK) throw std::runtime_error(g_err);
-            bzio::s1_copy(*ch, b.h_seq, b.h_qual, b.h_off, job.n_threads);
-            if (s1_launch(e, ch->slot, n, job.kit5 ? 1 : 0, job.umi_len) != BZ_OK) throw std::runtime_error(g_err);
-            clk.t[3] += bzio::StageClock::now() - t1;
-            inflight.push_back(std::move(ch));
-            ++n_chunks;
-        }
-        while (!inflight.empty()) {
-            auto old = std::move(inflight.front());
-            inflight.pop_front();
-            finish(std::move(old));
-        }
-        { std::lock_guard<std::mutex> g(W.mu); W.done = true; }
-        W.cv.notify_all();
-        writer.join();
-        if (W.failed) throw std::runtime_error(std::string("write error on ") + out_csv);
-        if (fo && fclose(fo) != 0) { fo = nullptr; throw std::runtime_error(std::string("write error on ") + out_csv); }
-        fo = nullptr;
+        pipe.run();
     } catch (const std::exception &e) {
         rc = fail(BZ_E_ARG, "%s", e.what());
     }
+    const int64_t n_chunks = pipe.n_chunks;
     if (getenv("BLAZE_AMD_IO_TIMING"))
         fprintf(stderr, "[bz_putative_bc_files] %.3f s total | reader thread %.3f | main: wait reader %.3f prepare %.3f pack+submit %.3f wait device %.3f "
                         "format %.3f hand-over %.3f | writer thread %.3f | %lld reads, %lld chunks, %d threads\n",
                 bzio::StageClock::now() - t_job, clk.t[0], clk.t[1], clk.t[2], clk.t[3], clk.t[4], clk.t[5], clk.t[6], clk.t[7],
                 (long long)reads_tot, (long long)n_chunks, n_threads);
-    const std::string keep = g_err;
-    shutdown();
-    g_err = keep;
     if (out_counts) {
         memset(out_counts, 0, 8 * sizeof(int64_t));
         out_counts[0] = reads_tot;

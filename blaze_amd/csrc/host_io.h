@@ -697,6 +697,141 @@ void parallel_for(int n_items, int n_threads, F &&fn) {
     if (err) std::rethrow_exception(err);
 }
 
+// ---- the frame both file jobs run in ------------------------------------------------------------------------------
+// reader thread -> queue (depth 2) -> the CALLING thread, which submits chunk k to its device slot and, once
+// `max_inflight` chunks are with the devices, finishes the oldest (waits for it, formats it) -> queue (depth 4) -> writer
+// thread.  Chunks are finished and written in the order they were read: the reference's ordered fan-out
+// (helper.py:177-205).  run() returns when everything is written and closed; on an error it stops both threads, lets the
+// device work of the chunks still in flight end (`abandon`), closes the file and rethrows.
+// StageClock slots it fills: 0 reader thread, 1 wait for the reader, 6 hand-over to the writer, 7 writer thread.
+template <class ChunkT>
+struct OrderedPipeline {
+    std::function<std::function<std::unique_ptr<ChunkT>()>()> open_reader;   // called ON the reader thread; its result yields chunks, nullptr at the end
+    std::function<void(ChunkT &, int64_t)> submit;                            // prepare the k-th chunk and start its device work
+    std::function<void(ChunkT &, std::vector<std::string> &)> finish;         // wait for the chunk's device work; its output parts, in order
+    std::function<void(ChunkT &)> abandon;                                    // wait for the device work of a chunk that will not be finished
+    std::string out_path;
+    bool create_output_first = true;             // false: the file is created when the first chunk is finished (a job without input leaves none)
+    int max_inflight = 2;
+    StageClock *clk = nullptr;
+    int64_t n_chunks = 0;
+
+    void run() {
+        struct { std::mutex mu; std::condition_variable cv; std::deque<std::unique_ptr<ChunkT>> q; bool done = false, stop = false; std::exception_ptr err; } Q;
+        struct { std::mutex mu; std::condition_variable cv; std::deque<std::vector<std::string>> q; bool done = false, failed = false; } W;
+        std::thread reader, writer;
+        std::deque<std::unique_ptr<ChunkT>> inflight;
+        FILE *fo = nullptr;
+        StageClock local;
+        StageClock &c = clk ? *clk : local;
+        auto open_out = [&]() {
+            if (fo) return;
+            fo = fopen(out_path.c_str(), "wb");
+            if (!fo) throw std::runtime_error("cannot open " + out_path + " for writing");
+        };
+        auto finish_oldest = [&]() {
+            auto old = std::move(inflight.front());
+            inflight.pop_front();
+            std::vector<std::string> parts;
+            finish(*old, parts);
+            const double t0 = StageClock::now();
+            open_out();
+            {
+                std::unique_lock<std::mutex> lk(W.mu);
+                W.cv.wait(lk, [&] { return W.q.size() < 4 || W.failed; });
+                if (W.failed) throw std::runtime_error("write error on " + out_path);
+                W.q.push_back(std::move(parts));
+            }
+            W.cv.notify_all();
+            c.t[6] += StageClock::now() - t0;
+        };
+        try {
+            if (create_output_first) open_out();
+            reader = std::thread([&]() {
+                try {
+                    auto next = open_reader();
+                    for (;;) {
+                        const double t0 = StageClock::now();
+                        auto ch = next();
+                        c.t[0] += StageClock::now() - t0;
+                        std::unique_lock<std::mutex> lk(Q.mu);
+                        if (!ch) break;
+                        Q.cv.wait(lk, [&] { return Q.q.size() < 2 || Q.stop; });
+                        if (Q.stop) return;
+                        Q.q.push_back(std::move(ch));
+                        Q.cv.notify_all();
+                    }
+                } catch (...) {
+                    std::lock_guard<std::mutex> g(Q.mu);
+                    Q.err = std::current_exception();
+                }
+                { std::lock_guard<std::mutex> g(Q.mu); Q.done = true; }
+                Q.cv.notify_all();
+            });
+            writer = std::thread([&]() {
+                for (;;) {
+                    std::vector<std::string> parts;
+                    {
+                        std::unique_lock<std::mutex> lk(W.mu);
+                        W.cv.wait(lk, [&] { return !W.q.empty() || W.done; });
+                        if (W.q.empty()) return;
+                        parts = std::move(W.q.front());
+                        W.q.pop_front();
+                    }
+                    W.cv.notify_all();
+                    const double t0 = StageClock::now();
+                    for (const std::string &part : parts)
+                        if (!part.empty() && !W.failed && fwrite(part.data(), 1, part.size(), fo) != part.size()) {
+                            std::lock_guard<std::mutex> g(W.mu);
+                            W.failed = true;
+                        }
+                    c.t[7] += StageClock::now() - t0;
+                }
+            });
+            for (int64_t k = 0;; ++k) {
+                std::unique_ptr<ChunkT> ch;
+                const double t0 = StageClock::now();
+                {
+                    std::unique_lock<std::mutex> lk(Q.mu);
+                    Q.cv.wait(lk, [&] { return !Q.q.empty() || Q.done; });
+                    if (Q.err) std::rethrow_exception(Q.err);
+                    if (Q.q.empty()) break;
+                    ch = std::move(Q.q.front());
+                    Q.q.pop_front();
+                }
+                Q.cv.notify_all();
+                c.t[1] += StageClock::now() - t0;
+                if ((int)inflight.size() == max_inflight) finish_oldest();      // the oldest chunk holds the slot this one takes
+                submit(*ch, k);
+                inflight.push_back(std::move(ch));
+                ++n_chunks;
+            }
+            while (!inflight.empty()) finish_oldest();
+            { std::lock_guard<std::mutex> g(W.mu); W.done = true; }
+            W.cv.notify_all();
+            writer.join();
+            if (W.failed) throw std::runtime_error("write error on " + out_path);
+            if (fo) {
+                FILE *f = fo;
+                fo = nullptr;
+                if (fclose(f) != 0) throw std::runtime_error("write error on " + out_path);
+            }
+            reader.join();
+        } catch (...) {
+            { std::lock_guard<std::mutex> g(Q.mu); Q.stop = true; }
+            Q.cv.notify_all();
+            if (reader.joinable()) reader.join();
+            { std::lock_guard<std::mutex> g(W.mu); W.done = true; }
+            W.cv.notify_all();
+            if (writer.joinable()) writer.join();
+            for (auto &ch : inflight) abandon(*ch);
+            inflight.clear();
+            if (fo) { fclose(fo); fo = nullptr; }
+            throw;
+        }
+    }
+};
+
 // ---- reader: FASTQ records + the same number of csv lines, cut into device batches of whole reference batches --
 class ChunkReader {
    public:

@@ -185,8 +185,9 @@ def test_gzip_member_sequence_line_trees():
 
 
 def test_host_threading_under_thread_sanitizer(tmp_path):
-    """tools/host_tsan.cpp (the job-long thread pool, the member encoder's per-thread buffers, the pool that inflates
-    gzipped inputs ahead of the reader) built with -fsanitize=thread: no report.  Host code only."""
+    """tools/host_tsan.cpp (the job-long thread pool, the member encoder's per-thread buffers, the ordered
+    reader / submit / finish / writer frame of the file jobs with a pretend device, the pool that inflates gzipped inputs
+    ahead of the reader) built with -fsanitize=thread: no report.  Host code only."""
     import shutil
     import subprocess
     import pytest
@@ -202,6 +203,7 @@ def test_host_threading_under_thread_sanitizer(tmp_path):
     r = subprocess.run([exe, str(tmp_path / "fq")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
     assert "lines 65000" in r.stdout and "caught 50" in r.stdout
+    assert r.stdout.count("as expected") == 5 and "WRONG" not in r.stdout      # the reader -> submit -> finish -> writer frame, every way of failing
 
 
 def test_host_parse_and_format_under_address_sanitizer(tmp_path):

@@ -8,6 +8,7 @@
 #include <cstdlib>
 int main(int argc, char **argv) {
     const std::string dir = argc > 1 ? argv[1] : "/tmp/host_tsan_fq";
+    if (system(("mkdir -p " + dir).c_str()) != 0) return 2;
     using namespace bzio;
     // 1. Pool: many short loops, nested scopes, exceptions
     {
@@ -32,6 +33,47 @@ int main(int argc, char **argv) {
             });
         size_t z = 0; for (auto &o : outs) z += o.size();
         printf("members %zu bytes\n", z);
+    }
+    // 1b. the ordered reader -> submit -> finish -> writer frame with a pretend device: output in order, and every way of failing
+    {
+        struct Ck { int k = 0; std::vector<int> v; };
+        for (int fail_at = -1; fail_at < 4; ++fail_at) {          // -1 = none; 0 reader, 1 submit, 2 finish, 3 unwritable output
+            Pool pool(4);
+            PoolScope sc(&pool);
+            OrderedPipeline<Ck> pipe;
+            pipe.out_path = fail_at == 3 ? dir + "/no/such/dir/out.txt" : dir + "/pipe_out.txt";
+            pipe.create_output_first = fail_at != 3;
+            pipe.max_inflight = 3;
+            std::atomic<int> abandoned{0};
+            pipe.open_reader = [&]() {
+                auto k = std::make_shared<int>(0);
+                return std::function<std::unique_ptr<Ck>()>([k, fail_at]() -> std::unique_ptr<Ck> {
+                    if (*k == 40) return nullptr;
+                    if (fail_at == 0 && *k == 17) throw std::runtime_error("reader");
+                    auto c = std::make_unique<Ck>();
+                    c->k = (*k)++;
+                    c->v.assign(100, c->k);
+                    return c;
+                });
+            };
+            pipe.submit = [&](Ck &c, int64_t k) { if (fail_at == 1 && k == 9) throw std::runtime_error("submit"); parallel_for(8, 4, [&](int i) { c.v[i] += 1; }); };
+            pipe.finish = [&](Ck &c, std::vector<std::string> &parts) {
+                if (fail_at == 2 && c.k == 21) throw MismatchError("finish");
+                parts.assign(3, "");
+                parallel_for(3, 4, [&](int i) { parts[i] = std::to_string(c.k) + "." + std::to_string(i) + "\n"; });
+            };
+            pipe.abandon = [&](Ck &) { ++abandoned; };
+            std::string what = "ok";
+            try { pipe.run(); } catch (const MismatchError &e) { what = std::string("mismatch:") + e.what(); } catch (const std::exception &e) { what = e.what(); }
+            std::string got;
+            if (FILE *f = fopen((dir + "/pipe_out.txt").c_str(), "rb")) { char buf[4096]; size_t n; while ((n = fread(buf, 1, sizeof buf, f)) > 0) got.append(buf, n); fclose(f); }
+            std::string want;
+            if (fail_at == -1) for (int k = 0; k < 40; ++k) for (int i = 0; i < 3; ++i) want += std::to_string(k) + "." + std::to_string(i) + "\n";
+            const bool ok = fail_at == -1 ? (what == "ok" && got == want && pipe.n_chunks == 40)
+                                          : (what != "ok" && (fail_at != 2 || what == "mismatch:finish"));
+            printf("pipeline fail_at %d: %s, abandoned %d, %s\n", fail_at, what.substr(0, 40).c_str(), abandoned.load(), ok ? "as expected" : "WRONG");
+            if (!ok) return 1;
+        }
     }
     // 2. FastqFiles prefetch pool with a tight budget
     {

@@ -104,6 +104,22 @@ int main(int argc, char **argv) {
                 for (auto &o : c.out) total_out += (long)o.size();
             }
         }
+        // ---- what a rank of a sharded run asks of its files: read counts, first ids, where a read's row starts in the table
+        {
+            int64_t reads = 0;
+            for (const std::string &f : fns) reads += count_fastq_reads(f);
+            if (reads != 257 + 1200) { printf("count_fastq_reads: %lld\n", (long long)reads); return 1; }
+            const std::string first = first_fastq_id(fns[2]);
+            if (first != "read257") { printf("first_fastq_id: %s\n", first.c_str()); return 1; }
+            if (!first_fastq_id(fns[1]).empty()) return 1;
+            if (variant != 4)                                       // a gzipped table cannot be searched: -1
+                for (double hint : {0.0, 0.17, 0.5, 1.0}) {
+                    const int64_t at = csv_locate_row(csv_path, first, hint);
+                    if (at <= 0 || csv.compare((size_t)at, first.size() + 1, first + ",") != 0) { printf("csv_locate_row(%g) = %lld\n", hint, (long long)at); return 1; }
+                    if (csv_locate_row(csv_path, "no_such_read", hint) != -1) return 1;
+                }
+            else if (csv_locate_row(csv_path, first, 0.5) != -1) return 1;
+        }
         // ---- stage 1 host side
         for (int mode = 0; mode < 2; ++mode) {
             S1Job job;

@@ -157,3 +157,66 @@ def test_noalloc_limits_and_invalid_rows(engine):
     finally:
         for b in bufs:
             b.free()
+
+
+def test_noalloc_under_stream_capture(engine):
+    """The call recorded into a HIP graph by stream capture in GLOBAL mode (an allocating or synchronising call from the
+    capturing thread would fail the capture) and the graph replayed on two different batches: what the entry point is for."""
+    H = hip()
+    for name in ("hipStreamCreateWithFlags", "hipStreamBeginCapture", "hipStreamEndCapture", "hipGraphInstantiate", "hipGraphLaunch",
+                 "hipStreamSynchronize", "hipGraphExecDestroy", "hipGraphDestroy", "hipStreamDestroy"):
+        getattr(H, name).restype = ctypes.c_int
+    H.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+    H.hipStreamBeginCapture.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    H.hipStreamEndCapture.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+    H.hipGraphInstantiate.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    H.hipGraphLaunch.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    H.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    H.hipGraphExecDestroy.argtypes = [ctypes.c_void_p]
+    H.hipGraphDestroy.argtypes = [ctypes.c_void_p]
+    H.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    n = 100_000
+    ext, el, bo, bl, wl = _workload(2 * n, 2000, seed=123)
+    engine.set_whitelist_codes16(wl)
+    for opt, v in ((_lib.BZ_OPT_SCAN_MODE, 0), (_lib.BZ_OPT_PAIR_FUSED, 0), (_lib.BZ_OPT_TIE_RULE, 0),
+                   (_lib.BZ_OPT_SHORTCUT, 1), (_lib.BZ_OPT_FORCE_GENERIC, 0)):
+        engine.set_option(opt, v)
+    stride = ext.shape[1]
+    bufs = [DevBuf(n * stride), DevBuf(n), DevBuf(n), DevBuf(n), DevBuf(4 * n), DevBuf(n), DevBuf(n), DevBuf(n)]
+    d_ext, d_len, d_off, d_bcl, d_hit, d_ed, d_end, d_flags = bufs
+    stream, graph, gexec = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    L = _lib.load()
+    try:
+        assert H.hipStreamCreateWithFlags(ctypes.byref(stream), 1) == 0           # hipStreamNonBlocking
+        assert H.hipStreamBeginCapture(stream, 0) == 0                            # hipStreamCaptureModeGlobal
+        rc = L.bz_assign_device_noalloc(engine._h, d_ext.ptr, stride, d_len.ptr, d_off.ptr, d_bcl.ptr, n, 2,
+                                        d_hit.ptr, d_ed.ptr, d_end.ptr, d_flags.ptr, stream)
+        end_rc = H.hipStreamEndCapture(stream, ctypes.byref(graph))
+        assert rc == 0, L.bz_last_error()
+        assert end_rc == 0 and graph.value
+        assert H.hipGraphInstantiate(ctypes.byref(gexec), graph, None, None, 0) == 0
+        for lo in (0, n):                                                         # the same graph on two different batches
+            e, l, o, b = ext[lo:lo + n], el[lo:lo + n], bo[lo:lo + n], bl[lo:lo + n]
+            engine.counts_reset()
+            ref = engine.assign(e, l, o, b, 2)
+            ref_counts = engine.counts()
+            engine.counts_reset()
+            d_ext.upload(e), d_len.upload(l), d_off.upload(o), d_bcl.upload(b)
+            for buf in (d_hit, d_ed, d_end, d_flags):
+                buf.fill(0x5A)
+            assert H.hipDeviceSynchronize() == 0
+            assert H.hipGraphLaunch(gexec, stream) == 0
+            assert H.hipStreamSynchronize(stream) == 0
+            got = (d_hit.download(np.int32, n), d_ed.download(np.int8, n), d_end.download(np.int8, n), d_flags.download(np.uint8, n))
+            for name, g, r in zip(("hit", "ed", "end", "flags"), got, ref):
+                assert np.array_equal(g, r), (lo, name)
+            assert np.array_equal(engine.counts(), ref_counts)
+    finally:
+        if gexec.value:
+            H.hipGraphExecDestroy(gexec)
+        if graph.value:
+            H.hipGraphDestroy(graph)
+        if stream.value:
+            H.hipStreamDestroy(stream)
+        for buf in bufs:
+            buf.free()

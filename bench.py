@@ -68,55 +68,31 @@ def launch_ranks(n, argv):
 
 
 class Plumbing:
-    """barrier / max / sum over ranks: RCCL through the C ABI; the host-side socket hub (blaze_amd.dist.Hub, which also
-    carries the RCCL id) when RCCL cannot be initialised -- `kind` says which and why."""
+    """barrier / max / sum over ranks on the job's communicator (blaze_amd.dist.make_comm): RCCL through the C ABI, or the
+    host-side socket hub when RCCL cannot be initialised on every rank -- `kind` says which and why."""
 
     def __init__(self, eng, rank, world, try_rccl=True):
-        self.rank, self.world, self.kind, self.eng = rank, world, "local", eng
-        self.rccl = None
-        self.hung = False
-        self.hub = dist.get_hub() if world > 1 else None
-        if world > 1 and not try_rccl:
+        self.rank, self.world, self.eng = rank, world, eng
+        self.comm = dist.make_comm(eng, try_rccl=try_rccl)
+        self.rccl = self.comm if self.comm.kind == "rccl" else None
+        self.hung = bool(getattr(self.comm, "hung", False))
+        if world == 1:
+            self.kind = "local"
+        elif self.rccl:
+            self.kind = "rccl"
+        elif not try_rccl:
             self.kind = "socket-hub (stand-in engine: no RCCL)"
-        elif world > 1:
-            # RCCL's init is collective and cannot be cancelled: run it on a daemon thread with a deadline, so that a
-            # bootstrap that never completes costs 90 s and a hub line instead of the whole measurement
-            import threading
-            box = {}
-
-            def init():
-                try:
-                    box["comm"] = dist.RcclComm(eng, rank, world)
-                except Exception as e:      # noqa: BLE001  (keep the bench alive, say what happened)
-                    box["err"] = e
-            t = threading.Thread(target=init, daemon=True)
-            t.start()
-            t.join(float(os.environ.get("BLAZE_AMD_RCCL_INIT_TIMEOUT", "90")))
-            mine = "rccl" if "comm" in box else (f"{type(box['err']).__name__}: {box['err']}" if "err" in box else "RCCL init did not finish in time")
-            self.hung = "comm" not in box and "err" not in box
-            # every rank must take the same route: one rank without RCCL sends all of them to the hub
-            states = self.hub.allgather(mine)
-            if all(x == "rccl" for x in states):
-                self.rccl, self.kind = box["comm"], "rccl"
-            else:
-                why = next(x for x in states if x != "rccl")
-                self.kind = f"socket-hub (RCCL unavailable: {why})"[:240]
+        else:
+            self.kind = f"socket-hub (RCCL unavailable: {self.comm.why})"[:240]
 
     def barrier(self):
-        if self.rccl:
-            self.rccl.barrier()
-        elif self.world > 1:
-            self.hub.allgather(0)
+        self.comm.barrier()
 
     def max(self, x):
-        if self.rccl:
-            return self.rccl.allreduce_max_f64(x)
-        return max(self.hub.allgather(float(x))) if self.world > 1 else float(x)
+        return self.comm.allreduce_max_f64(x)
 
     def sum_counts(self, local):
-        if self.world == 1:
-            return local
-        return np.sum(np.asarray(self.hub.allgather([int(v) for v in local]), dtype=np.int64), axis=0)
+        return self.comm.allreduce_sum_i64(np.asarray(local, dtype=np.int64))
 
 
 def cpu_baseline(ext, el, bo, bl, wl_bytes, max_ed, target_s=15.0):

@@ -418,12 +418,63 @@ def assign_read_sharded(comm, fastq_fns, fastq_out, putative_bc_csv, whitelsit_c
     return int(sums[0]), int(sums[1])
 
 
-def make_comm(engine=None):
-    """The communicator of this process: RCCL through the engine when launched with WORLD_SIZE > 1 on GPUs, else local."""
+class HubComm:
+    """The same four operations over the host-side socket hub: what the ranks fall back to when RCCL cannot be initialised
+    on every one of them (`why` says what RCCL reported).  A few scalars and short vectors per job, never the data path."""
+    kind = "socket-hub"
+
+    def __init__(self, hub, why=""):
+        self.hub, self.rank, self.world, self.why = hub, hub.rank, hub.world, why
+
+    def allreduce_sum_i64(self, arr):
+        a = np.ascontiguousarray(arr, dtype=np.int64)
+        parts = self.hub.allgather_bytes(a.tobytes())
+        return np.sum([np.frombuffer(p, dtype=np.int64) for p in parts], axis=0).reshape(a.shape)
+
+    def allreduce_max_f64(self, x):
+        return max(self.hub.allgather(float(x)))
+
+    def barrier(self):
+        self.hub.allgather(0)
+
+
+def make_comm(engine=None, try_rccl=True, init_timeout_s=None):
+    """The communicator of this process: local for one rank; RCCL through the engine when launched with WORLD_SIZE > 1
+    (one process per GPU); the socket hub when RCCL cannot be initialised on EVERY rank -- all ranks take the same route,
+    `comm.kind` / `comm.why` say which and why.  RCCL's init is collective and cannot be cancelled, so it runs on a daemon
+    thread with a deadline (BLAZE_AMD_RCCL_INIT_TIMEOUT, 90 s): a bootstrap that never completes costs the deadline, not
+    the job (`comm.hung` is then set: exit with os._exit, the thread is still inside RCCL)."""
     rank, world, _ = env_rank_world()
     if world == 1:
         return LocalComm()
-    return RcclComm(engine, rank, world)
+    hub = get_hub()
+    if not try_rccl:
+        comm = HubComm(hub, "RCCL not attempted")
+        comm.hung = False
+        return comm
+    import threading
+    box = {}
+
+    def init():
+        try:
+            eng = engine
+            if eng is None:                         # this process's engine: $BLAZE_AMD_DEVICES, else $LOCAL_RANK, else GPU 0
+                from . import read_assignment as ra
+                eng = ra.get_engine(ra._device_ids(None)[0])
+            box["comm"] = RcclComm(eng, rank, world)
+        except Exception as e:      # noqa: BLE001  (every rank must learn about it: reported through the hub below)
+            box["err"] = e
+    t = threading.Thread(target=init, daemon=True)
+    t.start()
+    t.join(float(init_timeout_s if init_timeout_s is not None else os.environ.get("BLAZE_AMD_RCCL_INIT_TIMEOUT", "90")))
+    mine = "rccl" if "comm" in box else (f"{type(box['err']).__name__}: {box['err']}" if "err" in box else "RCCL init did not finish in time")
+    states = hub.allgather(mine)
+    if all(x == "rccl" for x in states):
+        comm = box["comm"]
+    else:
+        comm = HubComm(hub, next(x for x in states if x != "rccl"))
+    comm.hung = "comm" not in box and "err" not in box
+    return comm
 
 
 # ---------------------------------------------------------------------------------------------- stage 1 over files

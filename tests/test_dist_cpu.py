@@ -2,6 +2,8 @@
 GPU, so the oracle stands in for the engine here (tests only); what is under test is the
 sharding, the order-preserving concatenation and the counts all-reduce."""
 import os
+
+import pytest
 import socket
 import subprocess
 import sys
@@ -394,3 +396,41 @@ def test_sharded_runs_ignore_parts_left_by_a_dead_run(tmp_path):
         assert len(res) == world
         assert open(out, "rb").read() == (b"fresh\n" if sharded == "step3" else b"header\nfresh\n")
         assert not [f for f in os.listdir(tmp_path) if ".part" in f]
+
+
+COMM_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np
+    from blaze_amd import dist
+
+    class NoRccl:                                   # an engine whose RCCL refuses (two ranks on one device, no library, ...)
+        @staticmethod
+        def comm_unique_id():
+            return bytes(128)
+        def comm_init(self, uid, world, rank):
+            if sys.argv[1] == "all" or rank == int(sys.argv[1]):
+                raise RuntimeError("ncclCommInitRank: invalid usage")
+        def comm_allreduce_f64(self, v, op):        # (RcclComm's own barrier right after a successful init)
+            return v
+
+    dist.RcclComm.__init__.__globals__["Engine"] = NoRccl          # RcclComm asks the engine class for the id
+    import blaze_amd.engine as eng_mod
+    eng_mod.Engine = NoRccl
+    comm = dist.make_comm(NoRccl(), init_timeout_s=20)
+    assert comm.kind == "socket-hub" and "invalid usage" in comm.why and not comm.hung, (comm.kind, getattr(comm, "why", ""))
+    v = comm.allreduce_sum_i64(np.arange(5, dtype=np.int64) * (comm.rank + 1) + (1 << 60))
+    assert v.tolist() == [int(k * 3 + (1 << 61)) for k in range(5)], v            # exact above 2^53
+    assert comm.allreduce_max_f64(1.5 + comm.rank) == 2.5
+    comm.barrier()
+    print("rank", comm.rank, "ok")
+""") % ROOT
+
+
+@pytest.mark.parametrize("who", ["1", "all"])
+def test_make_comm_falls_back_to_the_hub_on_every_rank(tmp_path, who):
+    """dist.make_comm: when RCCL cannot be initialised on one rank (or on all), EVERY rank takes the socket hub -- same
+    sums (exact int64), max and barrier -- and says why."""
+    script = tmp_path / "comm_worker.py"
+    script.write_text(COMM_WORKER)
+    _launch_two(script, who)

@@ -25,6 +25,8 @@ def worker(d, gz, threads):
     out = os.path.join(d, f"sharded_w{comm.world}.fastq" + (".gz" if gz else ""))
     best = None
     for rep in range(3):
+        if comm.rank == 0 and os.path.exists(out):
+            os.remove(out)                          # dropping the last repetition's 1.7 GB is not part of a run
         comm.barrier()
         t0 = time.perf_counter()
         got = dist.assign_read_sharded(comm, fns, out, os.path.join(d, "putative_bc.csv"), os.path.join(d, "whitelist.csv"), 2, threads, 1000)

@@ -54,12 +54,12 @@ def draw_whitelist(rng, n_cells, family_frac):
 
 
 def draw_case(rng, big=False):
-    """big: one case in eight takes a whitelist of 46,000 ... 70,000 entries (the streaming pair-seeded kernel instead of
-    the two-kernel path) with a few hundred rows."""
+    """big: one case in eight takes a whitelist of 4,000 ... 70,000 entries (long candidate lists of the two-kernel path, and
+    above ~45,000 the streaming pair-seeded kernel) with a few hundred rows."""
     n_cells = int(rng.choice([1, 2, 3, 5, 31, 63, 64, 65, 127, 200, 257, 777, 1024, 2048, 3001]))
     large = big and rng.random() < 0.125
     if large:
-        n_cells = int(rng.integers(46_000, 70_000))
+        n_cells = int(rng.integers(4_000, 70_000))          # both sides of the candidate-list limit (~45k) and of 65,536
     family = float(rng.choice([0.0, 0.2, 0.6]))
     wl = draw_whitelist(rng, n_cells, family)
     err = float(rng.choice([0.5, 1.0, 3.0, 6.0]))
@@ -167,7 +167,7 @@ def main():
         bad = np.flatnonzero((hit != o_hit) | (ed != o_ed) | (end != o_end) | ((flags & FLAG_MASK) != o_flag))
         n_cases += 1
         n_rows += ext.shape[0]
-        key = f"ed{p['max_ed']}_m{p['scan_mode']}" + ("_big" if p["n_cells"] > 40_000 else "")
+        key = f"ed{p['max_ed']}_m{p['scan_mode']}" + ("_big" if p["n_cells"] > 3_500 else "")
         stats[key] = stats.get(key, 0) + 1
         if bad.size:
             n_fail += 1

@@ -634,9 +634,7 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
     // more than kMaxIrregular send every row through the byte-wise scan
     constexpr int64_t kMaxIrregular = 256;
     std::vector<int32_t> reg_pos, irr_pos;
-    bool empty_entry = false;
     for (int64_t k = 0; k < n; ++k) {
-        empty_entry = empty_entry || offsets[k + 1] == offsets[k];
         bool ok = offsets[k + 1] - offsets[k] == bz::kBcLen;
         const char *w = bytes + offsets[k];
         for (int i = 0; ok && i < bz::kBcLen; ++i) ok = w[i] == 'A' || w[i] == 'C' || w[i] == 'G' || w[i] == 'T';
@@ -644,9 +642,9 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
         else if ((int64_t)irr_pos.size() <= kMaxIrregular) irr_pos.push_back((int32_t)k);
     }
     const int64_t nf = (int64_t)reg_pos.size();
-    // (an empty entry is a falsy hit in the reference's fold and event words hold the index in 25 bits: such lists take
-    // the byte-wise scan as a whole when they are not all regular)
-    const bool regular = nf > 0 && (nf == n || (n - nf <= kMaxIrregular && !empty_entry && n < ((int64_t)1 << 23)));   // k_fix_rows' event words: 23 bits of index at max_ed > 3
+    // (an empty entry -- a blank line of the list -- is one of the irregular entries: at distance 0 from every text and a
+    // falsy hit in the reference's fold, fold_update_falsy; every scored row is then re-scored by k_fix_rows)
+    const bool regular = nf > 0 && (nf == n || (n - nf <= kMaxIrregular && n < ((int64_t)1 << 23)));   // k_fix_rows' event words: 23 bits of index at max_ed > 3
     const bool mixed = regular && nf < n;
     // byte form (generic kernel + histogram size)
     std::vector<int64_t> off(n + 1);

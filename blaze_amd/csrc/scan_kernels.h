@@ -131,6 +131,18 @@ __device__ __forceinline__ void fold_update(int ed, int end_idx, int idx, int &b
     }
 }
 
+// The same with an EMPTY whitelist entry in play (a blank line of --known-bc-list: '' is within distance 0 of every
+// text, and as `bc_hit` it is falsy, so `if not bc_hit` of :76 lets the next tie replace it and :87 reports no hit).
+__device__ __forceinline__ void fold_update_falsy(int ed, int end_idx, int idx, bool empty, int &best, int &hit, int &hit_end,
+                                                  bool &hit_empty, bool &done) {
+    if (done) return;
+    if (ed < best) { best = ed; hit = idx; hit_end = end_idx; hit_empty = empty; }
+    else if (ed == best) {
+        if (hit == kHitNone || hit_empty) { hit = idx; hit_end = end_idx; hit_empty = empty; }
+        else { hit = kHitAmbiguous; hit_empty = false; best -= 1; if (best < 0) done = true; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Full-rate instruction selection (measured on MI355X, tools/valu_microbench.hip): with all-VGPR
 // operands v_xor/v_and/v_or/v_add_u32 and the 3-input v_bitop3_b32 issue at the SIMD-32 rate
@@ -1368,8 +1380,22 @@ struct GenericShared {
     unsigned long long mn[2][kGenericMaxK + 1];
     uint32_t xh[kGenericMax], xl[kGenericMax], v[kGenericMax], peq[4];
     int exact;
+    int empty;                                                    // smallest index of an empty entry (mixed lists), or INT_MAX
     uint8_t text[kGenericMax];
 };
+constexpr int kNoIndex = 0x7FFFFFFF;
+
+// Which EMPTY entries can reach the fold.  Distance-0 events in whitelist order: a run of empties is one falsy hit (each
+// replaces the one before it), the first non-empty entry n1 replaces that, and whatever distance-0 event comes next --
+// empty or not -- makes the read ambiguous and ends the fold.  So beside the two smallest non-empty events per class only
+// the first empty entry (if in front of n1) and the first empty entry behind n1 matter.
+__device__ inline void relevant_empties(const int2 *__restrict__ irr_meta, int n_irr, int first_empty, int n1, int &e_a, int &e_b) {
+    e_a = first_empty < n1 ? first_empty : kNoIndex;
+    e_b = kNoIndex;
+    if (first_empty != kNoIndex && n1 != kNoIndex)
+        for (int k = 0; k < n_irr; ++k)
+            if (irr_meta[k].x == 0 && irr_meta[k].y > n1 && irr_meta[k].y < e_b) e_b = irr_meta[k].y;
+}
 
 template <int K>
 __device__ __forceinline__ void generic_row_wg(const GenericArgs &a, int r, GenericShared &sh) {
@@ -1386,6 +1412,7 @@ __device__ __forceinline__ void generic_row_wg(const GenericArgs &a, int r, Gene
     }
     if (tid < 4) sh.peq[tid] = 0u;
     if (tid == 4) sh.exact = 0x7FFFFFFF;
+    if (tid == 5) sh.empty = kNoIndex;
     if (tid < 2 * (kGenericMaxK + 1)) (&sh.mn[0][0])[tid] = ~0ull;
     __syncthreads();
     if (len < kBcLen && tid < len && sh.v[tid]) atomicOr(&sh.peq[base_code(sh.text[tid])], 1u << tid);   // the text as the pattern
@@ -1445,6 +1472,7 @@ __device__ __forceinline__ void generic_row_wg(const GenericArgs &a, int r, Gene
         if (ed <= K) note(a.reg_to_orig ? a.reg_to_orig[sub] : sub, ed, best_end);
     }
     for (int k = tid; k < a.n_irr; k += 256) {
+        if (a.irr_meta[k].x == 0) { atomicMin(&sh.empty, a.irr_meta[k].y); continue; }   // '' : distance 0 from any text, only the first one matters
         int end;
         const int ed = dev_sub_edit_distance(a.irr_bytes + a.irr_off[k], a.irr_meta[k].x, row, len, K, a.tie, end);
         if (ed <= K) note(a.irr_meta[k].y, ed, end);
@@ -1460,13 +1488,18 @@ __device__ __forceinline__ void generic_row_wg(const GenericArgs &a, int r, Gene
     }
     __syncthreads();
     if (tid == 0) {
-        unsigned long long ev[2 * (K + 1)];
+        unsigned long long ev[2 * (K + 1) + 2];
         int nev = 0;
 #pragma unroll
         for (int c = 0; c <= K; ++c) {
             if (sh.mn[0][c] != ~0ull) ev[nev++] = sh.mn[0][c];
             if (sh.mn[1][c] != ~0ull) ev[nev++] = sh.mn[1][c];
         }
+        // empty entries: events of distance 0 whose end field (255) marks them as falsy
+        int e_a, e_b;
+        relevant_empties(a.irr_meta, a.n_irr, sh.empty, sh.mn[0][0] != ~0ull ? (int)(sh.mn[0][0] >> 16) : kNoIndex, e_a, e_b);
+        if (e_a != kNoIndex) ev[nev++] = ((unsigned long long)(uint32_t)e_a << 16) | 255ull;
+        if (e_b != kNoIndex) ev[nev++] = ((unsigned long long)(uint32_t)e_b << 16) | 255ull;
         for (int x = 1; x < nev; ++x) {                           // whitelist order = order of the words (index in the top bits)
             const unsigned long long v = ev[x];
             int y = x - 1;
@@ -1474,12 +1507,15 @@ __device__ __forceinline__ void generic_row_wg(const GenericArgs &a, int r, Gene
             ev[y + 1] = v;
         }
         int best = K, hit = kHitNone, hit_end = -1;
-        bool done = false;
-        for (int x = 0; x < nev; ++x)
-            fold_update((int)((ev[x] >> 8) & 0xFFu), (int)(ev[x] & 0xFFu) - 1, (int)(ev[x] >> 16), best, hit, hit_end, done);
-        a.hit[r] = hit >= 0 ? hit : -1;
+        bool done = false, hit_empty = false;
+        for (int x = 0; x < nev; ++x) {
+            const int e = (int)(ev[x] & 0xFFu);
+            fold_update_falsy((int)((ev[x] >> 8) & 0xFFu), e == 255 ? -1 : e - 1, (int)(ev[x] >> 16), e == 255, best, hit, hit_end, hit_empty, done);
+        }
+        const bool ok = hit >= 0 && !hit_empty;
+        a.hit[r] = ok ? hit : -1;
         a.ed[r] = (int8_t)best;
-        a.end[r] = (int8_t)(hit >= 0 ? hit_end : -1);
+        a.end[r] = (int8_t)(ok ? hit_end : -1);
         a.flags[r] = (uint8_t)(kFlagGeneric | (hit == kHitAmbiguous ? kFlagAmbig : 0u));
     }
     __syncthreads();                                              // the shared state is reused by the workgroup's next row
@@ -1525,8 +1561,9 @@ __global__ __launch_bounds__(256) void k_pair_tail(
 // An irregular entry of 1..32 characters that is not longer than the text is scored bit-parallel too: the text of a
 // scored row is all ACGT, so four match masks per entry (bit i: entry[i] is that letter; any other character matches
 // nothing) drive the same K-error Shift-And; its accept bit sits at the entry's last character.  Longer entries (the text
-// then is the pattern, as in the replaced FFI) take the byte-wise DP.  Empty entries are not admitted to this path (an
-// empty hit is falsy in the reference's fold; such a list takes the byte-wise scan as a whole).
+// then is the pattern, as in the replaced FFI) take the byte-wise DP.  An EMPTY entry (a blank line of the list) is at
+// distance 0 from every text -- every scored row is re-scored -- and a falsy hit in the reference's fold:
+// fold_update_falsy / relevant_empties.
 constexpr int kEndNone = 31;                                      // event words hold end + 0..19, or this for "no column" (end -1)
 
 template <int K>
@@ -1581,6 +1618,7 @@ __global__ __launch_bounds__(256) void k_mixed_fix(
         const uint64_t tc = row_codes(load_row(row, ext_stride), len);
         bool near = false;
         for (int k = 0; k < n_irr && !near; ++k) {
+            if (irr_meta[k].x == 0) { near = true; break; }      // '' is at distance 0 from every text
             int ed, end;
             irr_exact<K>(irr_peq[k], irr_meta[k].x, irr_bytes + irr_off[k], row, tc, len, tie, ed, end);
             near = ed <= K;
@@ -1598,6 +1636,8 @@ __global__ __launch_bounds__(256) void k_fix_rows(
     const int32_t *__restrict__ fix_list, const int32_t *__restrict__ n_fix_ptr, int tie,
     int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
     __shared__ uint32_t s_min[2][K + 1];
+    __shared__ int s_empty;                                       // smallest index of an empty entry, or kNoIndex
+    constexpr int kEndEmpty = 30;                                 // end field of the empty entry's event (a real end is <= 19)
     constexpr int kEdBits = K <= 3 ? 2 : 4;                       // event word: index | ed | end (5 bits); 25 / 23 bits of index (host checks)
     const int n_fix = *n_fix_ptr;
     const int tid = threadIdx.x;
@@ -1632,13 +1672,17 @@ __global__ __launch_bounds__(256) void k_fix_rows(
             exact_pair<K>(p & 0xFFFFu, p >> 16, XH, XL, len, tie, ed, end);
             if (ed <= K) note(reg_to_orig[sub], ed, end);
         }
+        int my_empty = kNoIndex;
         for (int k = tid; k < n_irr; k += 256) {
+            if (irr_meta[k].x == 0) { my_empty = min(my_empty, irr_meta[k].y); continue; }   // '' (see generic_row_wg)
             int ed, end;
             irr_exact<K>(irr_peq[k], irr_meta[k].x, irr_bytes + irr_off[k], row, tc, len, tie, ed, end);
             if (ed <= K) note(irr_meta[k].y, ed, end);
         }
         if (tid <= K) { s_min[0][tid] = 0xFFFFFFFFu; s_min[1][tid] = 0xFFFFFFFFu; }
+        if (tid == 0) s_empty = kNoIndex;
         __syncthreads();
+        if (my_empty != kNoIndex) atomicMin(&s_empty, my_empty);
 #pragma unroll
         for (int c = 0; c <= K; ++c) if (keep[c][0] != 0xFFFFFFFFu) atomicMin(&s_min[0][c], keep[c][0]);
         __syncthreads();
@@ -1650,13 +1694,17 @@ __global__ __launch_bounds__(256) void k_fix_rows(
         }
         __syncthreads();
         if (tid == 0) {
-            uint32_t ev[2 * (K + 1)];
+            uint32_t ev[2 * (K + 1) + 2];
             int nev = 0;
 #pragma unroll
             for (int c = 0; c <= K; ++c) {
                 if (s_min[0][c] != 0xFFFFFFFFu) ev[nev++] = s_min[0][c];
                 if (s_min[1][c] != 0xFFFFFFFFu) ev[nev++] = s_min[1][c];
             }
+            int e_a, e_b;
+            relevant_empties(irr_meta, n_irr, s_empty, s_min[0][0] != 0xFFFFFFFFu ? (int)(s_min[0][0] >> (5 + kEdBits)) : kNoIndex, e_a, e_b);
+            if (e_a != kNoIndex) ev[nev++] = ((uint32_t)e_a << (5 + kEdBits)) | (uint32_t)kEndEmpty;
+            if (e_b != kNoIndex) ev[nev++] = ((uint32_t)e_b << (5 + kEdBits)) | (uint32_t)kEndEmpty;
             for (int a = 1; a < nev; ++a) {                       // whitelist order = order of the words (index in the top bits)
                 const uint32_t v = ev[a];
                 int b = a - 1;
@@ -1664,14 +1712,16 @@ __global__ __launch_bounds__(256) void k_fix_rows(
                 ev[b + 1] = v;
             }
             int best = K, hit = kHitNone, hit_end = -1;
-            bool done = false;
+            bool done = false, hit_empty = false;
             for (int a = 0; a < nev; ++a) {
                 const int e = (int)(ev[a] & 31u);
-                fold_update((int)((ev[a] >> 5) & ((1u << kEdBits) - 1u)), e == kEndNone ? -1 : e, (int)(ev[a] >> (5 + kEdBits)), best, hit, hit_end, done);
+                fold_update_falsy((int)((ev[a] >> 5) & ((1u << kEdBits) - 1u)), (e == kEndNone || e == kEndEmpty) ? -1 : e,
+                                  (int)(ev[a] >> (5 + kEdBits)), e == kEndEmpty, best, hit, hit_end, hit_empty, done);
             }
-            hit_out[r] = hit >= 0 ? hit : -1;
+            const bool ok = hit >= 0 && !hit_empty;
+            hit_out[r] = ok ? hit : -1;
             ed_out[r] = (int8_t)best;
-            end_out[r] = (int8_t)(hit >= 0 ? hit_end : -1);
+            end_out[r] = (int8_t)(ok ? hit_end : -1);
             flags_out[r] = (uint8_t)(hit == kHitAmbiguous ? kFlagAmbig : 0u);
         }
         __syncthreads();                                          // s_min is reused by the workgroup's next row

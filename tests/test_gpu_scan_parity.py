@@ -260,6 +260,39 @@ def test_irregular_whitelist(engine, oracle):
     _compare(engine, oracle, ext, el, bo, bl, wl_list, 1, tie=1)
 
 
+@pytest.mark.parametrize("where", ["front", "middle", "end", "twice"])
+@pytest.mark.parametrize("max_ed", [0, 1, 2, 3, 5])
+def test_blank_line_in_the_whitelist(engine, oracle, max_ed, where):
+    """A blank line of --known-bc-list becomes the entry '' (read_assignment.py:286-289): at distance 0 from every text, and
+    as `bc_hit` falsy -- the next tie replaces it (:76) and :87 reports no hit.  The list keeps its fast-path structures
+    (the empty entry is one of the irregular ones), every scored row is re-scored by the workgroup-per-row kernel with the
+    falsy rule, and rows that hold a barcode verbatim one column off (distance 0 without the shortcut) tie with it on
+    either side.  Equal to the oracle on every row, both tie rules, irregular rows included."""
+    rows, wl = _synthetic(3000, 400, err=3.0, seed=57)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    wl_list = [w.tobytes() for w in wl]
+    rng = np.random.default_rng(8)
+    scored = np.flatnonzero((bl == 16) & (el == 20))
+    for r in scored[::7]:                               # a barcode verbatim at columns 3..18, the row says 2..17
+        w = np.frombuffer(wl_list[int(rng.integers(0, len(wl_list)))], dtype=np.uint8)
+        ext[r, 3:19] = w
+    ext[scored[3], 5] = ord("N")                        # and two irregular rows
+    el[scored[10]] = 18
+    ext[scored[10], 18:] = 0
+    pos = {"front": [0], "middle": [200], "end": [len(wl_list)], "twice": [150, 320]}[where]
+    for p in reversed(pos):
+        wl_list.insert(p, b"")
+    for tie in (0, 1):
+        hit, ed, end, flags = _compare(engine, oracle, ext, el, bo, bl, wl_list, max_ed, tie)
+    t = engine.timing(0)
+    assert t["rows_bitparallel"] > 500 and t["rows_mixed_fix"] == t["rows_bitparallel"]      # the packed kernels ran, every scored row was re-scored
+    n_scored_hits = int(((hit >= 0) & ((flags & _lib.BZ_F_EXACT) == 0)).sum())
+    if where == "front":
+        assert n_scored_hits > 20        # '' first: falsy, a distance-0 barcode behind it replaces it and is assigned
+    if where == "end":
+        assert n_scored_hits == 0        # '' last: it ties with (or undercuts) whatever was found before it
+
+
 @pytest.mark.parametrize("scan_mode", **MODES)
 @pytest.mark.parametrize("max_ed", [2, 1])
 def test_mixed_whitelist_keeps_the_fast_path(engine, oracle, max_ed, scan_mode):

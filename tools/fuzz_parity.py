@@ -113,6 +113,11 @@ def draw_case(rng, big=False):
                 el[r] = int(rng.integers(18, 20))
             elif k == 7:
                 ext[r, 16:18] = ext[r, 18:20]; el[r] = 18; bl[r] = 14
+            elif k == 8 and rng.random() < 0.5:                   # a barcode verbatim one column to the right of where the row says it is:
+                w = np.frombuffer(wl[int(rng.integers(0, n_cells))], dtype=np.uint8)   # distance 0 without the shortcut
+                if w.size == 16:
+                    ext[r, :] = 0; ext[r, 0:3] = ACGT[rng.integers(0, 4, 3)]; ext[r, 3:19] = w; ext[r, 19] = ACGT[rng.integers(0, 4)]
+                    el[r], bo[r], bl[r] = 20, 2, 16
             elif k == 8:                                          # an exact copy of an entry, barcode at offset 1
                 w = np.frombuffer(wl[int(rng.integers(0, n_cells))], dtype=np.uint8)
                 ext[r, :] = 0; ext[r, 0] = ACGT[rng.integers(0, 4)]; ext[r, 1:17] = w; ext[r, 17:19] = ACGT[rng.integers(0, 4, 2)]
@@ -121,11 +126,11 @@ def draw_case(rng, big=False):
     mixed = rng.random() < 0.3
     if mixed:
         for _ in range(int(rng.integers(1, 6))):
-            k = int(rng.integers(0, 5))
+            k = int(rng.integers(0, 6))
             base = wl[int(rng.integers(0, len(wl)))]
             if len(base) != 16:
                 continue
-            new = [base[:15], base + b"AC", base[:6] + b"N" + base[7:], base.lower(), base[:12]][k]
+            new = [base[:15], base + b"AC", base[:6] + b"N" + base[7:], base.lower(), base[:12], b""][k]   # b"": a blank line of the list
             pos = int(rng.integers(0, len(wl) + 1))
             if rng.random() < 0.5 and len(wl) > 1:
                 wl[wl.index(base)] = new                           # replaces its parent

@@ -26,3 +26,15 @@ for n_irr in (0, 1, 5, 50, 250):
     dt = (time.perf_counter() - t0) / 30
     eng.set_option(_lib.BZ_OPT_PROFILE, 1); eng.run(0, 2); t = eng.timing(0); eng.set_option(_lib.BZ_OPT_PROFILE, 0)
     print(f"irregular entries {n_irr:3d}: {dt * 1e3:.3f} ms/step, rows scored {t['rows_bitparallel']}, re-scored over the whole list {t['rows_mixed_fix']}, generic {t['rows_generic']}")
+# a blank line of the list: '' is at distance 0 from every text, so EVERY scored row is re-scored by the workgroup-per-row kernel
+lst = list(wl) + [b""]
+eng.set_whitelist(lst)
+eng.stage(0, ext, el, bo, bl)
+eng.run(0, 2)
+eng.sync(0)
+t0 = time.perf_counter()
+for _ in range(3): eng.run(0, 2)
+eng.sync(0)
+dt = (time.perf_counter() - t0) / 3
+eng.set_option(_lib.BZ_OPT_PROFILE, 1); eng.run(0, 2); t = eng.timing(0); eng.set_option(_lib.BZ_OPT_PROFILE, 0)
+print(f"a blank line ('' entry): {dt * 1e3:.3f} ms/step, rows scored {t['rows_bitparallel']}, re-scored over the whole list {t['rows_mixed_fix']}")

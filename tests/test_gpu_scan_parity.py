@@ -248,7 +248,7 @@ def test_bytes_past_the_text_are_ignored(engine, oracle, scan_mode):
 
 def test_irregular_whitelist(engine, oracle):
     """Whitelist with an N barcode, a 15-mer, an 18-mer and an empty string.  The empty string is within any max_ed of
-    every text, so the mixed path re-scores every scored row over the whole list: slow, and exact."""
+    every text, so the mixed path re-scores every scored row over the whole list (workgroup per row, falsy-hit rule)."""
     rows, wl = _synthetic(800, 60, err=2.0, seed=14)
     ext, el, bo, bl = synth.pack_ext(rows)
     wl_list = [w.tobytes() for w in wl]

@@ -73,10 +73,6 @@ def _rendezvous_key():
     return f"{os.environ.get('MASTER_ADDR', 'local')}_{os.environ.get('MASTER_PORT', '0')}" + (f"_{run}" if run else "")
 
 
-def _rendezvous_path():
-    return os.path.join(os.environ.get("BLAZE_AMD_RDZV_DIR", "/tmp"), f"blaze_amd_rccl_{_rendezvous_key()}.id")
-
-
 def _recv_exact(sock, n):
     buf = bytearray()
     while len(buf) < n:
@@ -214,31 +210,6 @@ def get_hub():
         rank, world, _ = env_rank_world()
         _hub = Hub(rank, world)
     return _hub
-
-
-def exchange_unique_id_file(rank: int, make_id, timeout_s: float = 120.0) -> bytes:
-    """Second channel for the 128-byte RCCL id when the hub's port cannot be used: rank 0 writes it to a file named
-    after (MASTER_ADDR, MASTER_PORT[, run id]); the other ranks poll for a fresh one."""
-    path = _rendezvous_path()
-    if rank == 0:
-        uid = make_id()
-        tmp = path + f".tmp{os.getpid()}"
-        with open(tmp, "wb") as f:
-            f.write(uid)
-        os.replace(tmp, path)
-        return uid
-    start = time.time()
-    while True:
-        try:
-            st = os.stat(path)
-            if st.st_size == 128 and st.st_mtime >= start - 120:
-                with open(path, "rb") as f:
-                    return f.read()
-        except FileNotFoundError:
-            pass
-        if time.time() - start > timeout_s:
-            raise TimeoutError(f"no RCCL id at {path} after {timeout_s}s")
-        time.sleep(0.02)
 
 
 def exchange_unique_id(rank: int, make_id, timeout_s: float = 120.0) -> bytes:

@@ -152,14 +152,12 @@ def test_world_size_2_gloo(tmp_path):
         assert f"rank {rank} ok" in out
 
 
-def test_file_rendezvous_roundtrip(tmp_path, monkeypatch):
+def test_rendezvous_key_has_no_pids(monkeypatch):
     from blaze_amd import dist
-    monkeypatch.setenv("BLAZE_AMD_RDZV_DIR", str(tmp_path))
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
     monkeypatch.setenv("MASTER_PORT", "12345")
-    uid = bytes(range(128))
-    assert dist.exchange_unique_id_file(0, lambda: uid) == uid
-    assert dist.exchange_unique_id_file(1, None, timeout_s=5) == uid
-    assert str(os.getppid()) not in os.path.basename(dist._rendezvous_path())      # ranks need not share a parent
+    key = dist._rendezvous_key()
+    assert "12345" in key and str(os.getppid()) not in key and str(os.getpid()) not in key      # ranks need not share a parent
 
 
 def test_hub_allgather_three_ranks():

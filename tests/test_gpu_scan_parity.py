@@ -587,11 +587,10 @@ def test_full_10x_whitelist_stress(engine, oracle):
     assert ((flags & _lib.BZ_F_AMBIG) != 0).sum() > 0
 
 
-def test_rccl_single_rank_collective(engine, tmp_path, monkeypatch):
+def test_rccl_single_rank_collective(engine):
     """The one collective of the path (per-barcode counts + [assigned, total]) through RCCL itself, world size 1:
-    librccl is dlopen'ed, the id goes through the rendezvous file, the all-reduce runs on the device."""
+    librccl is dlopen'ed, the id comes from ncclGetUniqueId, the all-reduce runs on the device."""
     from blaze_amd import dist
-    monkeypatch.setenv("BLAZE_AMD_RDZV_DIR", str(tmp_path))
     rows, wl = _synthetic(3000, 120, seed=17)
     ext, el, bo, bl = synth.pack_ext(rows)
     engine.set_whitelist([w.tobytes() for w in wl])

@@ -631,8 +631,8 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
 
     const int64_t total = n ? offsets[n] - offsets[0] : 0;
     // entries of the packed shape (16-nt ACGT) in caller order; a FEW others beside them keep the fast path (k_mixed_fix),
-    // more than kMaxIrregular send every row through the byte-wise scan
-    constexpr int64_t kMaxIrregular = 256;
+    // more than kMaxIrregular (or no regular entry at all) send every row through the byte-wise scan
+    constexpr int64_t kMaxIrregular = 65536;          // (k_mixed_fix probes every scored row against each of them: ~6 us per entry per 1M rows)
     std::vector<int32_t> reg_pos, irr_pos;
     for (int64_t k = 0; k < n; ++k) {
         bool ok = offsets[k + 1] - offsets[k] == bz::kBcLen;

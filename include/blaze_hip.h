@@ -141,7 +141,7 @@ int bz_slot_sync(bz_handle h, int slot);
  * another scan ran); counts[0] rows, [1] rows scored by the
  * bit-parallel kernels, [2] rows scored by the generic kernel, [3] whitelist size, [4] rows the seeded
  * scan handed to the filtered scan (more than 8 near matches), [5] rows of a MIXED whitelist (regular entries + at most
- * 256 irregular ones, a blank line's empty entry included) that came within max_ed of an irregular entry and were re-scored over the whole list. */
+ * 65,536 irregular ones, a blank line's empty entry included) that came within max_ed of an irregular entry and were re-scored over the whole list. */
 int bz_slot_timing(bz_handle h, int slot, float ms[8], int64_t counts[8]);
 
 /* ---- the entry point that allocates nothing ------------------------------------------------------------------

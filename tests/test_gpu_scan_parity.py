@@ -357,16 +357,19 @@ def test_mixed_whitelist_odd_entries(engine, oracle, max_ed, tie):
         assert t["rows_mixed_fix"] == t["rows_bitparallel"]          # "A" is within one edit of any text
 
 
-def test_too_many_irregular_entries_take_the_generic_scan(engine, oracle):
+def test_list_without_a_regular_entry_takes_the_generic_scan(engine, oracle):
+    """No 16-nt ACGT entry at all (here: every barcode cut to 15 nt): no fast-path structure can be built, every row takes
+    the one-lane byte-wise scan.  Three quarters irregular, on the other hand, keeps the fast path for the regular quarter."""
     rows, wl = _synthetic(600, 400, err=2.0, seed=72)
     ext, el, bo, bl = synth.pack_ext(rows)
-    wl_list = [w.tobytes() for w in wl]
-    for k in range(0, 400, 1):
-        if k % 4 != 3:
-            wl_list[k] = wl_list[k][:15]            # 300 irregular entries: above the limit of the mixed path
+    wl_list = [w.tobytes()[:15] for w in wl]
     _compare(engine, oracle, ext, el, bo, bl, wl_list, 2)
     t = engine.timing(0)
     assert t["rows_bitparallel"] == 0 and t["rows_generic"] > 300
+    wl_list = [w.tobytes() if k % 4 == 3 else w.tobytes()[:15] for k, w in enumerate(wl)]      # 300 irregular entries of 400
+    _compare(engine, oracle, ext, el, bo, bl, wl_list, 2)
+    t = engine.timing(0)
+    assert t["rows_bitparallel"] > 300 and t["rows_generic"] == 0
 
 
 def test_near_duplicate_whitelist_order_dependence(engine, oracle):
@@ -634,3 +637,26 @@ def test_submit_pinned_equals_submit(engine):
     finally:
         for b in bufs:
             b.free()
+
+
+@pytest.mark.parametrize("max_ed", [1, 2, 4])
+def test_whitelist_with_hundreds_of_irregular_entries(engine, oracle, max_ed):
+    """A list where 40 % of the entries are outside the packed shape (15-mers, 17-mers, an N, lower case -- variants of the
+    regular ones, so most rows come near some of them): the regular entries keep their seeded kernels, every row near an
+    irregular entry is re-scored over the whole list; equal to the oracle on every row."""
+    rows, wl = _synthetic(2500, 600, err=3.0, seed=61)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    wl_list = [w.tobytes() for w in wl]
+    rng = np.random.default_rng(13)
+    for k in range(400):
+        w = wl_list[int(rng.integers(0, len(wl_list)))]
+        if len(w) != 16 or not w.isupper() or b"N" in w:
+            continue
+        new = [w[:15], w + b"A", w[:5] + b"N" + w[6:], w.lower()][k % 4]
+        wl_list.insert(int(rng.integers(0, len(wl_list) + 1)), new)
+    n_irr = sum(1 for w in wl_list if len(w) != 16 or not set(w) <= set(b"ACGT"))
+    assert n_irr > 300
+    for tie in (0, 1):
+        _compare(engine, oracle, ext, el, bo, bl, wl_list, max_ed, tie)
+    t = engine.timing(0)
+    assert t["rows_bitparallel"] > 500 and t["rows_generic"] == 0 and t["rows_mixed_fix"] > 100

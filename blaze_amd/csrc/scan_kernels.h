@@ -1363,7 +1363,7 @@ __global__ void k_scan_generic(const uint8_t *__restrict__ wl_bytes, const int64
 // the entries; a regular entry is scored bit-parallel in registers -- the text's per-column masks come from LDS, a
 // column that is not ACGT matches nothing (exactly what the byte compare of the reference's library does) -- with the
 // roles the replaced FFI takes: the barcode is the pattern unless the text is shorter than 16, then the text is the
-// pattern and the barcode's 16 characters the columns.  Irregular entries (mixed lists, <= 256) take the byte-wise DP,
+// pattern and the barcode's 16 characters the columns.  Irregular entries (mixed lists) take the byte-wise DP,
 // one per lane.  The exact-match shortcut (`row.putative_bc in whitelist`, :61) is a byte compare over the list, smallest
 // index wins.  As everywhere, the two smallest events per distance class decide the fold: lanes keep two per class,
 // 64-bit LDS atomicMin picks the workgroup's (word = index << 16 | ed << 8 | end + 1), one lane replays the fold.

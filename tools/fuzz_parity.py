@@ -125,7 +125,8 @@ def draw_case(rng, big=False):
     ext[np.arange(32)[None, :] >= el[:, None]] = 0
     mixed = rng.random() < 0.3
     if mixed:
-        for _ in range(int(rng.integers(1, 6))):
+        n_odd = int(rng.integers(1, 6)) if rng.random() > 0.15 else int(rng.integers(260, 700))     # a few, or hundreds
+        for _ in range(n_odd):
             k = int(rng.integers(0, 6))
             base = wl[int(rng.integers(0, len(wl)))]
             if len(base) != 16:

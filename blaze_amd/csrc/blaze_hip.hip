@@ -133,7 +133,8 @@ struct bz_engine {
     int64_t n_wl = -1;
     int wl_regular = 0;                 // the packed fast path is usable (every entry 16-nt ACGT, or all but a few: `mixed`)
     int64_t n_fast = 0;                 // entries the fast-path structures below are built over (the regular ones, in caller order)
-    int mixed = 0, n_irr = 0;           // a few irregular entries beside the regular ones (k_mixed_fix)
+    int mixed = 0, n_irr = 0;           // irregular entries beside the regular ones (k_mixed_fix)
+    int irr_only = 0;                   // a list WITHOUT a regular entry (<= 65,536 entries): every row through the workgroup-per-row scan
     int32_t *d_reg_to_orig = nullptr;   //   sub-list index -> index in the caller's list
     uint8_t *d_irr_bytes = nullptr;     //   the irregular entries, back to back
     int64_t *d_irr_off = nullptr;
@@ -214,7 +215,7 @@ void free_whitelist(bz_handle h) {
     h->pair_cap = 0;
     hipFree(h->d_reg_to_orig); hipFree(h->d_irr_bytes); hipFree(h->d_irr_off); hipFree(h->d_irr_peq); hipFree(h->d_irr_meta);
     h->d_reg_to_orig = nullptr; h->d_irr_bytes = nullptr; h->d_irr_off = nullptr; h->d_irr_peq = nullptr; h->d_irr_meta = nullptr;
-    h->mixed = 0; h->n_irr = 0; h->n_fast = 0;
+    h->mixed = 0; h->irr_only = 0; h->n_irr = 0; h->n_fast = 0;
     h->d_planes = nullptr; h->d_sorted_codes = nullptr; h->d_sorted_idx = nullptr;
     h->d_wl_bytes = nullptr; h->d_wl_off = nullptr; h->d_counts = nullptr;
     h->n_wl = -1;
@@ -355,7 +356,8 @@ bz::GenericArgs generic_args(bz_handle h, const Slot &s) {
     bz::GenericArgs a;
     a.wl_bytes = h->d_wl_bytes; a.wl_off = h->d_wl_off; a.n_wl = (int)h->n_wl;
     a.planes32 = h->d_planes32; a.n_fast = (int)h->n_fast; a.reg_to_orig = h->mixed ? h->d_reg_to_orig : nullptr;
-    a.irr_meta = h->d_irr_meta; a.irr_bytes = h->d_irr_bytes; a.irr_off = h->d_irr_off; a.n_irr = h->mixed ? h->n_irr : 0;
+    a.irr_meta = h->d_irr_meta; a.irr_bytes = h->d_irr_bytes; a.irr_off = h->d_irr_off; a.irr_peq = h->d_irr_peq;
+    a.n_irr = (h->mixed || h->irr_only) ? h->n_irr : 0;
     a.ext = s.d_ext; a.ext_stride = s.stride; a.ext_len = s.d_len; a.bc_off = s.d_off; a.bc_len = s.d_bcl;
     a.tie = h->tie_rule; a.shortcut = h->shortcut;
     a.hit = s.d_hit; a.ed = s.d_ed; a.end = s.d_end; a.flags = s.d_flags;
@@ -497,7 +499,7 @@ int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed
     }
     if (prof) HIP_TRY(hipEventRecord(s.ev[2], s.stream));
     if (!s.tail_done) {
-        if (h->wl_regular && max_ed <= bz::kGenericMaxK) {
+        if ((h->wl_regular || h->irr_only) && max_ed <= bz::kGenericMaxK) {
             // irregular rows (every row when max_ed is 4..8) against a list with the fast-path structures: a workgroup per
             // row, bit-parallel per entry
             const dim3 ggrid(std::min(n, 4 * h->n_cu));
@@ -825,7 +827,12 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
             }
         }
         h->n_fast = nf;
-        if (mixed) {
+    }
+    // the irregular entries: bytes, four match masks and {length, caller's index} each -- beside regular entries (mixed), or
+    // the whole of a list that has no regular entry
+    const bool irr_only = !regular && nf == 0 && n > 0 && n <= kMaxIrregular;
+    if (mixed || irr_only) {
+        {
             std::vector<char> ib;
             std::vector<int64_t> io(1, 0);
             std::vector<uint4> peq;
@@ -846,13 +853,13 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
             HIP_TRY(hipMalloc(&h->d_irr_meta, meta.size() * sizeof(int2)));
             HIP_TRY(hipMemcpy(h->d_irr_peq, peq.data(), peq.size() * sizeof(uint4), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(h->d_irr_meta, meta.data(), meta.size() * sizeof(int2), hipMemcpyHostToDevice));
-            HIP_TRY(hipMalloc(&h->d_reg_to_orig, nf * sizeof(int32_t)));
+            HIP_TRY(hipMalloc(&h->d_reg_to_orig, std::max<int64_t>(nf, 1) * sizeof(int32_t)));
             HIP_TRY(hipMalloc(&h->d_irr_bytes, std::max<size_t>(ib.size(), 1)));
             HIP_TRY(hipMalloc(&h->d_irr_off, io.size() * sizeof(int64_t)));
-            HIP_TRY(hipMemcpy(h->d_reg_to_orig, reg_pos.data(), nf * sizeof(int32_t), hipMemcpyHostToDevice));
+            if (nf) HIP_TRY(hipMemcpy(h->d_reg_to_orig, reg_pos.data(), nf * sizeof(int32_t), hipMemcpyHostToDevice));
             if (!ib.empty()) HIP_TRY(hipMemcpy(h->d_irr_bytes, ib.data(), ib.size(), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(h->d_irr_off, io.data(), io.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-            h->mixed = 1; h->n_irr = (int)irr_pos.size();
+            h->mixed = mixed ? 1 : 0; h->irr_only = irr_only ? 1 : 0; h->n_irr = (int)irr_pos.size();
         }
     }
     h->n_wl = n;

@@ -1367,10 +1367,37 @@ __global__ void k_scan_generic(const uint8_t *__restrict__ wl_bytes, const int64
 // one per lane.  The exact-match shortcut (`row.putative_bc in whitelist`, :61) is a byte compare over the list, smallest
 // index wins.  As everywhere, the two smallest events per distance class decide the fold: lanes keep two per class,
 // 64-bit LDS atomicMin picks the workgroup's (word = index << 16 | ed << 8 | end + 1), one lane replays the fold.
+// One irregular whitelist entry against a plain-ACGT text of <= 32 columns (tc: its 2-bit codes): bit-parallel through the
+// entry's four match masks when the entry is the pattern (1..32 characters, not longer than the text); the byte-wise DP
+// otherwise (the text then is the pattern).  See the mixed-whitelist kernels below.
+template <int K>
+__device__ __forceinline__ void irr_exact(const uint4 peq, int m, const uint8_t *__restrict__ entry, const uint8_t *__restrict__ row,
+                                          uint64_t tc, int len, int tie, int &ed, int &end) {
+    if (m >= 1 && m <= 32 && m <= len) {
+        ShiftAnd<K, 1u> A;
+        A.init();
+        const uint32_t acc = 1u << (m - 1);
+        int best_cnt = m <= K ? K + 1 - m : 0, best_end = -1;     // before any column: every character deleted, D[m][0] = m
+        for (int j = 0; j < len; ++j) {
+            const uint32_t code = (uint32_t)(tc >> (2 * j)) & 3u;
+            const uint32_t eq = code == 0u ? peq.x : code == 1u ? peq.y : code == 2u ? peq.z : peq.w;
+            A.step(eq);
+            int cnt = 0;
+#pragma unroll
+            for (int d = 0; d <= K; ++d) cnt += (A.R[d] & acc) != 0u;
+            if (cnt > best_cnt || (tie && cnt == best_cnt && cnt > 0)) { best_cnt = cnt; best_end = j; }
+        }
+        ed = K + 1 - best_cnt;
+        end = ed <= K ? best_end : -1;
+    } else {
+        ed = dev_sub_edit_distance(entry, m, row, len, K, tie, end);
+    }
+}
+
 struct GenericArgs {
     const uint8_t *wl_bytes; const int64_t *wl_off; int n_wl;            // the whole list in the caller's order (shortcut compare)
     const uint32_t *planes32; int n_fast; const int32_t *reg_to_orig;   // its regular entries (reg_to_orig null: all of it)
-    const int2 *irr_meta; const uint8_t *irr_bytes; const int64_t *irr_off; int n_irr;
+    const int2 *irr_meta; const uint8_t *irr_bytes; const int64_t *irr_off; const uint4 *irr_peq; int n_irr;
     const uint8_t *ext; int ext_stride; const uint8_t *ext_len, *bc_off, *bc_len;
     int tie, shortcut;
     int32_t *hit; int8_t *ed; int8_t *end; uint8_t *flags;
@@ -1380,6 +1407,7 @@ struct GenericShared {
     unsigned long long mn[2][kGenericMaxK + 1];
     uint32_t xh[kGenericMax], xl[kGenericMax], v[kGenericMax], peq[4];
     int exact;
+    int odd_columns;                                              // columns of the text that are not ACGT
     int empty;                                                    // smallest index of an empty entry (mixed lists), or INT_MAX
     uint8_t text[kGenericMax];
 };
@@ -1413,9 +1441,11 @@ __device__ __forceinline__ void generic_row_wg(const GenericArgs &a, int r, Gene
     if (tid < 4) sh.peq[tid] = 0u;
     if (tid == 4) sh.exact = 0x7FFFFFFF;
     if (tid == 5) sh.empty = kNoIndex;
+    if (tid == 6) sh.odd_columns = 0;
     if (tid < 2 * (kGenericMaxK + 1)) (&sh.mn[0][0])[tid] = ~0ull;
     __syncthreads();
     if (len < kBcLen && tid < len && sh.v[tid]) atomicOr(&sh.peq[base_code(sh.text[tid])], 1u << tid);   // the text as the pattern
+    if (tid < len && !sh.v[tid]) atomicAdd(&sh.odd_columns, 1);
     if (a.shortcut) {
         for (int k = tid; k < a.n_wl; k += 256) {
             const int64_t o = a.wl_off[k];
@@ -1471,10 +1501,17 @@ __device__ __forceinline__ void generic_row_wg(const GenericArgs &a, int r, Gene
         const int ed = K + 1 - best_cnt;
         if (ed <= K) note(a.reg_to_orig ? a.reg_to_orig[sub] : sub, ed, best_end);
     }
+    // irregular entries: bit-parallel through their four match masks when the text is plain ACGT of <= 32 columns (what a
+    // list without regular entries meets on every ordinary row); the byte-wise DP otherwise
+    const bool plain_text = sh.odd_columns == 0 && len >= 1 && len <= 32;
+    uint64_t tc = 0;
+    if (plain_text && a.n_irr > 0)
+        for (int j = 0; j < len; ++j) tc |= (uint64_t)base_code(sh.text[j]) << (2 * j);
     for (int k = tid; k < a.n_irr; k += 256) {
-        if (a.irr_meta[k].x == 0) { atomicMin(&sh.empty, a.irr_meta[k].y); continue; }   // '' : distance 0 from any text, only the first one matters
-        int end;
-        const int ed = dev_sub_edit_distance(a.irr_bytes + a.irr_off[k], a.irr_meta[k].x, row, len, K, a.tie, end);
+        if (a.irr_meta[k].x == 0) { atomicMin(&sh.empty, a.irr_meta[k].y); continue; }   // '' : distance 0 from any text
+        int ed, end;
+        if (plain_text) irr_exact<K>(a.irr_peq[k], a.irr_meta[k].x, a.irr_bytes + a.irr_off[k], row, tc, len, a.tie, ed, end);
+        else ed = dev_sub_edit_distance(a.irr_bytes + a.irr_off[k], a.irr_meta[k].x, row, len, K, a.tie, end);
         if (ed <= K) note(a.irr_meta[k].y, ed, end);
     }
 #pragma unroll
@@ -1565,30 +1602,6 @@ __global__ __launch_bounds__(256) void k_pair_tail(
 // distance 0 from every text -- every scored row is re-scored -- and a falsy hit in the reference's fold:
 // fold_update_falsy / relevant_empties.
 constexpr int kEndNone = 31;                                      // event words hold end + 0..19, or this for "no column" (end -1)
-
-template <int K>
-__device__ __forceinline__ void irr_exact(const uint4 peq, int m, const uint8_t *__restrict__ entry, const uint8_t *__restrict__ row,
-                                          uint64_t tc, int len, int tie, int &ed, int &end) {
-    if (m >= 1 && m <= 32 && m <= len) {
-        ShiftAnd<K, 1u> A;
-        A.init();
-        const uint32_t acc = 1u << (m - 1);
-        int best_cnt = m <= K ? K + 1 - m : 0, best_end = -1;     // before any column: every character deleted, D[m][0] = m
-        for (int j = 0; j < len; ++j) {
-            const uint32_t code = (uint32_t)(tc >> (2 * j)) & 3u;
-            const uint32_t eq = code == 0u ? peq.x : code == 1u ? peq.y : code == 2u ? peq.z : peq.w;
-            A.step(eq);
-            int cnt = 0;
-#pragma unroll
-            for (int d = 0; d <= K; ++d) cnt += (A.R[d] & acc) != 0u;
-            if (cnt > best_cnt || (tie && cnt == best_cnt && cnt > 0)) { best_cnt = cnt; best_end = j; }
-        }
-        ed = K + 1 - best_cnt;
-        end = ed <= K ? best_end : -1;
-    } else {
-        ed = dev_sub_edit_distance(entry, m, row, len, K, tie, end);
-    }
-}
 
 // the text of a regular row: 2-bit codes (column j at bits 2j) from its bytes
 __device__ __forceinline__ uint64_t row_codes(const RowBytes &rb, int len) {

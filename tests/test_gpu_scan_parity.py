@@ -357,19 +357,23 @@ def test_mixed_whitelist_odd_entries(engine, oracle, max_ed, tie):
         assert t["rows_mixed_fix"] == t["rows_bitparallel"]          # "A" is within one edit of any text
 
 
-def test_list_without_a_regular_entry_takes_the_generic_scan(engine, oracle):
-    """No 16-nt ACGT entry at all (here: every barcode cut to 15 nt): no fast-path structure can be built, every row takes
-    the one-lane byte-wise scan.  Three quarters irregular, on the other hand, keeps the fast path for the regular quarter."""
+def test_list_without_a_regular_entry(engine, oracle):
+    """No 16-nt ACGT entry at all (here: every barcode cut to 15 nt): no seed index can be built, every row takes the
+    workgroup-per-row scan (entries scored bit-parallel through their match masks on plain-ACGT rows, byte-wise on the
+    others).  Three quarters irregular, on the other hand, keeps the seeded kernels for the regular quarter."""
     rows, wl = _synthetic(600, 400, err=2.0, seed=72)
     ext, el, bo, bl = synth.pack_ext(rows)
-    wl_list = [w.tobytes()[:15] for w in wl]
-    _compare(engine, oracle, ext, el, bo, bl, wl_list, 2)
-    t = engine.timing(0)
-    assert t["rows_bitparallel"] == 0 and t["rows_generic"] > 300
+    ext[7, 4] = ord("N"); ext[11, 9] |= 0x20                  # two rows that are not plain ACGT: byte-wise inside the same kernel
+    for cut in (lambda w: w[:15], lambda w: w + b"AC", lambda w: w.lower(), lambda w: w[:3] + b"N" + w[4:]):
+        wl_list = [cut(w.tobytes()) for w in wl]
+        for max_ed, tie in ((2, 0), (1, 1), (4, 0), (9, 0)):             # 9: above the kernel's range, the one-lane scan
+            _compare(engine, oracle, ext, el, bo, bl, wl_list, max_ed, tie)
+        t = engine.timing(0)
+        assert t["rows_bitparallel"] == 0 and t["rows_generic"] > 300
     wl_list = [w.tobytes() if k % 4 == 3 else w.tobytes()[:15] for k, w in enumerate(wl)]      # 300 irregular entries of 400
     _compare(engine, oracle, ext, el, bo, bl, wl_list, 2)
     t = engine.timing(0)
-    assert t["rows_bitparallel"] > 300 and t["rows_generic"] == 0
+    assert t["rows_bitparallel"] > 300 and t["rows_generic"] == 2          # the two rows that are not plain ACGT
 
 
 def test_near_duplicate_whitelist_order_dependence(engine, oracle):

@@ -137,6 +137,9 @@ def draw_case(rng, big=False):
                 wl[wl.index(base)] = new                           # replaces its parent
             else:
                 wl.insert(pos, new)
+    if rng.random() < 0.04 and len(wl) <= 5000:              # a list without one regular entry: 15-mers, 17-mers or lower case
+        kind = int(rng.integers(0, 3))
+        wl = [(w[:15] if kind == 0 else w + b"A" if kind == 1 else w.lower()) if len(w) == 16 else w for w in wl]
     max_ed = int(rng.choice([0, 1, 2, 2, 2, 3, 3, 4, 5, 6, 7, 8]))
     params = dict(n_cells=len(wl), family=family, err=err, n_rows=n_rows, irregular_rows=bool(irregular_rows), mixed=bool(mixed),
                   max_ed=max_ed, tie=int(rng.integers(0, 2)), shortcut=bool(rng.random() < 0.8),

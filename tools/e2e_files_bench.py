@@ -5,7 +5,6 @@ and BASELINE configs[4]'s shape (10-nt UMI, 10k cells, restrand + trim).
 
 usage: python tools/e2e_files_bench.py [n_reads] [n_cells] [threads] [--gz] [--python-too]
 """
-import gzip
 import json
 import os
 import sys

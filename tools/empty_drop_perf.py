@@ -1,7 +1,6 @@
 """SURVEY 8f N4 measurement: bz_far_from_all (candidates x cells global edit distance, cut-off 5) vs the oracle's C loop."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 from blaze_amd import synth, whitelisting
 from blaze_amd.engine import Engine
 from oracle import oracle as o

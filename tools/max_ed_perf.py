@@ -1,7 +1,6 @@
 """Step time of the product path per --max-edit-distance (1M rows x 5,000 cells, rows resident, one slot)."""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
-import numpy as np
 from blaze_amd import synth
 from blaze_amd.engine import Engine
 full = synth.full_whitelist_codes(400_000, seed=1)

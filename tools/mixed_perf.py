@@ -2,7 +2,6 @@
 what k_mixed_fix + the re-scored rows cost (1M rows, rows resident, one slot)."""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
-import numpy as np
 from blaze_amd import synth, _lib
 from blaze_amd.engine import Engine
 full = synth.full_whitelist_codes(400_000, seed=1)

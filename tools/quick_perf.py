@@ -1,7 +1,6 @@
 """Ad-hoc perf probe (not part of bench.py): scan kernel timing at a few sizes."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 from blaze_amd import synth, _lib
 from blaze_amd.engine import Engine, device_info
 

@@ -27,7 +27,6 @@ eng = Engine(0)
 putative_bc.search(eng, seqs[:1000], quals[:1000], "3v3", 12)
 t0 = time.time(); code, strand, start, minq, polyt = putative_bc.search(eng, seqs, quals, "3v3", 12); dt = time.time() - t0
 print(f"device (python packing + H2D + kernel + D2H): {n} reads, {total / 1e6:.0f} MB in {dt:.3f} s = {n / dt / 1e3:.0f} K reads/s; found {int((code == 0).sum())}")
-import ctypes
 from blaze_amd import _lib
 enc = [s.encode() for s in seqs]; off = np.zeros(n + 1, np.int64); np.cumsum([len(s) for s in enc], out=off[1:])
 sb = np.frombuffer(b"".join(enc), np.uint8); qb = np.full(sb.size, ord("I"), np.uint8)

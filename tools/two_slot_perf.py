@@ -2,7 +2,7 @@
 the engine's double buffering) with the rows resident in HBM."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from blaze_amd import synth, _lib
+from blaze_amd import synth
 from blaze_amd.engine import Engine
 
 n_rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000

@@ -3,7 +3,7 @@ native host pipeline (bz_assign_files) vs the pandas host that mirrors the refer
 metric (that one is HBM-resident); this is the PCIe + file-system + host-CPU inclusive figure of SURVEY 8f N1/N2
 and BASELINE configs[4]'s shape (10-nt UMI, 10k cells, restrand + trim).
 
-usage: python tools/e2e_files_bench.py [n_reads] [n_cells] [threads] [--gz] [--python-too]
+usage: python tools/e2e_files_bench.py [n_reads] [n_cells] [threads] [--gz] [--gz-in] [--n-files=N] [--python-too]
 """
 import json
 import os
@@ -30,10 +30,14 @@ def main():
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
         t0 = time.time()
         n_files = 64 if "--gz-in" in sys.argv else 4
+        for a in sys.argv:
+            if a.startswith("--n-files="):
+                n_files = int(a.split("=")[1])
         fns, pc, wl, fq_bytes = write_inputs(d, n, n_cells, n_files=n_files)
         if "--gz-in" in sys.argv:                       # a nanopore run's shape: many .fastq.gz files of a few thousand reads
             import subprocess
-            subprocess.check_call(["gzip", "-1"] + fns)
+            for lo in range(0, len(fns), 256):
+                subprocess.check_call(["gzip", "-1"] + fns[lo:lo + 256])
             fns = [f + ".gz" for f in fns]
         gen_s = time.time() - t0
         out = {"reads": n, "cells": n_cells, "threads": threads, "gz": gz, "gz_in": "--gz-in" in sys.argv, "n_files": n_files, "fastq_bytes": fq_bytes, "generate_s": gen_s,

@@ -99,7 +99,9 @@ int bz_set_option(bz_handle h, int option, int64_t value);
  * read_assignment.py:206,314.  `bytes` holds the barcodes back to back, barcode k is
  * bytes[offsets[k] .. offsets[k+1]).  ORDER IS SEMANTIC (the fold of :66-85 is
  * order dependent) and is kept exactly as given; the caller passes list(set(whitelist)).
- * 16-nt ACGT lists are packed 2 bits/base into the bit-plane layout the kernel streams. */
+ * 16-nt ACGT entries are packed 2 bits/base into the bit-plane layout the kernels stream and get the seed indices;
+ * any other line the reference would accept (read_assignment.py:286-289: other lengths, other letters, a blank line)
+ * is kept as an irregular entry beside them -- up to 65,536 -- and scored exactly (same results, slower rows). */
 int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int64_t n);
 
 /* Rows.  Row r is the extension ext[r*ext_stride .. +ext_len[r]) =

@@ -1421,8 +1421,10 @@ static int assign_files_impl(bz_handle *engines, int n_engines, const char *cons
         const double t2 = bzio::StageClock::now();
         clk.t[2] += t2 - t1;
         c.engine = (int)(k % n_engines); c.slot = (int)((k / n_engines) % 2);
-        if (bz_assign_submit(engines[c.engine], c.slot, c.ext.data(), bzio::kExtStride, c.ext_len.data(), c.bc_off.data(),
-                             c.bc_len.data(), (int64_t)n, max_ed) != BZ_OK)
+        const bool wide = !c.wide.empty();
+        if (wide) bzio::widen_rows(c);
+        if (bz_assign_submit(engines[c.engine], c.slot, wide ? c.ext_wide.data() : c.ext.data(), wide ? bzio::kExtWide : bzio::kExtStride,
+                             c.ext_len.data(), c.bc_off.data(), c.bc_len.data(), (int64_t)n, max_ed) != BZ_OK)
             throw std::runtime_error(g_err);
         clk.t[3] += bzio::StageClock::now() - t2;
     };

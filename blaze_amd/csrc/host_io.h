@@ -513,6 +513,11 @@ struct Chunk {
     std::vector<Span> bc, umi, post, rid;
     std::vector<double> polyT;               // NaN = blank cell
     std::vector<uint8_t> ext, ext_len, bc_off, bc_len;
+    // rows whose extension does not fit kExtStride (a hand-made table: stage 1 only writes 16-nt barcodes): their
+    // pre_bc_flanking cell, kept so that the chunk can be packed again at kExtWide bytes per row (widen_rows)
+    std::mutex wide_mu;
+    std::vector<std::pair<uint32_t, Span>> wide;
+    std::vector<uint8_t> ext_wide;
     // filled by the device
     std::vector<int32_t> hit;
     std::vector<int8_t> ed, end_idx;
@@ -524,6 +529,7 @@ struct Chunk {
 };
 
 constexpr int kExtStride = 32;
+constexpr int kExtWide = 64;                 // BZ_EXT_MAX: the device's longest row, and the pandas host's limit (_pack_rows)
 
 inline bool is_na_token(const char *s, uint32_t n) {   // pandas' default na_values (parsers STR_NA_VALUES)
     static const char *const toks[] = {"", "#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN", "-NaN", "-nan", "1.#IND", "1.#QNAN",
@@ -949,7 +955,14 @@ inline void parse_batch(Chunk &ch, int b) {
         if (cell[1].len == 0) { ch.ext_len[r] = ch.bc_off[r] = ch.bc_len[r] = 0; continue; }     // blank row (:61)
         const uint32_t npre = std::min<uint32_t>(pre.len, 2), numi = std::min<uint32_t>(cell[3].len, 2);
         const uint32_t total = npre + cell[1].len + numi;
-        if (total > kExtStride) throw std::runtime_error("putative_bc longer than the device row (28 nt)");
+        if (total > kExtStride) {
+            if (total > kExtWide || cell[1].len > kExtWide)
+                throw std::runtime_error("putative_bc row: extension of " + std::to_string(total) + " nt exceeds the device limit of " + std::to_string(kExtWide));
+            ch.ext_len[r] = (uint8_t)total; ch.bc_off[r] = (uint8_t)npre; ch.bc_len[r] = (uint8_t)cell[1].len;
+            std::lock_guard<std::mutex> g(ch.wide_mu);
+            ch.wide.emplace_back(r, pre);
+            continue;
+        }
         memcpy(e, pre.p + pre.len - npre, npre);
         memcpy(e + npre, cell[1].p, cell[1].len);
         memcpy(e + npre + cell[1].len, cell[3].p, numi);
@@ -957,6 +970,23 @@ inline void parse_batch(Chunk &ch, int b) {
     }
     if (all_numeric_ids && hi > lo)       // pandas would have made read_id a numeric column: `bc.read_id != r.id` (:220)
         throw MismatchError("Different order in putative bc file and input fastq!");
+}
+
+// a chunk with rows wider than kExtStride: every row again at kExtWide bytes (after all its batches are parsed)
+inline void widen_rows(Chunk &ch) {
+    const size_t n = ch.reads.size();
+    ch.ext_wide.assign(n * kExtWide, 0);
+    for (size_t r = 0; r < n; ++r)
+        if (ch.ext_len[r] <= kExtStride) memcpy(ch.ext_wide.data() + r * kExtWide, ch.ext.data() + r * kExtStride, kExtStride);
+    for (const auto &w : ch.wide) {
+        const uint32_t r = w.first;
+        const Span pre = w.second;
+        uint8_t *e = ch.ext_wide.data() + (size_t)r * kExtWide;
+        const uint32_t npre = ch.bc_off[r], nbc = ch.bc_len[r], numi = (uint32_t)ch.ext_len[r] - npre - nbc;
+        memcpy(e, pre.p + pre.len - npre, npre);
+        memcpy(e + npre, ch.bc[r].p, nbc);
+        memcpy(e + npre + nbc, ch.umi[r].p, numi);
+    }
 }
 
 inline void gzip_member(const std::string &in, std::string &out, int level) {

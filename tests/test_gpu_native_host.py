@@ -68,7 +68,7 @@ def test_native_end_to_end_golden(tmp_path, device_batch_rows, threads):
         assert (int(demul), int(total)) == (exp["demul"], exp["total"])
 
 
-def _make_files(tmp_path, n, n_cells, seed, *, crlf=False, float_polyT=True, quirks=True, n_files=3, err=2.0, umi_len=12):
+def _make_files(tmp_path, n, n_cells, seed, *, crlf=False, float_polyT=True, quirks=True, n_files=3, err=2.0, umi_len=12, wide=False):
     """Synthetic step-3 inputs: FASTQ files (second one gzipped), putative_bc.csv, whitelist."""
     rng = np.random.default_rng(seed)
     full = synth.full_whitelist_codes(20_000, seed=seed + 1)
@@ -124,6 +124,10 @@ def _make_files(tmp_path, n, n_cells, seed, *, crlf=False, float_polyT=True, qui
                 pe_s = f"{pe}.7"                # int() truncates toward zero
             elif k == 10:
                 post = "null"
+            elif k == 11 and wide:              # a hand-made barcode cell wider than the 32-byte row (up to the device's 64)
+                m = int(rng.integers(17, 61))
+                bc = (bc + "".join("ACGT"[c] for c in rng.integers(0, 4, size=m)))[:m] if rng.integers(0, 2) else \
+                    ("".join("ACGT"[c] for c in rng.integers(0, 4, size=m - 16)) + bc)[-m:]
         lines.append(f"{ids[i]},{bc},{q},{umi},{pe_s},{pre},{post}\n")
     nl = "\r\n" if crlf else "\n"
     csv = "".join(lines).replace("\n", nl)
@@ -360,3 +364,51 @@ def test_two_engines_in_one_process_alternate_chunks(tmp_path, gz):
             assert _text(two) == _text(one)
     finally:
         e1.close()
+
+
+def test_rows_wider_than_the_packed_row(tmp_path):
+    """A hand-made table may hold putative barcodes of any length (stage 1 only writes 16 nt).  The native host packs
+    rows of up to 32 bytes; a chunk with a longer one is packed again at 64, the device's and the pandas host's limit,
+    and gives the pandas host's bytes; beyond 64 both hosts refuse."""
+    n = 3000
+    fns, pc, pw, _ = _make_files(tmp_path, n, 200, seed=909, quirks=False, n_files=2)
+    wl = [w.split('-')[0].strip() for w in open(pw)]
+    rng = np.random.default_rng(4)
+    lines = open(pc).read().splitlines(keepends=True)
+    rnd = lambda k: "".join("ACGT"[c] for c in rng.integers(0, 4, size=k))
+    n_wide = 0
+    for i in range(1, len(lines)):
+        cells = lines[i].rstrip("\n").split(",")
+        if not cells[1] or rng.integers(0, 6):
+            continue
+        k = int(rng.integers(0, 4))
+        if k == 0:
+            cells[1] = rnd(int(rng.integers(1, 20))) + wl[int(rng.integers(0, len(wl)))] + rnd(int(rng.integers(1, 20)))   # a cell inside a long cell
+        elif k == 1:
+            cells[1] = rnd(int(rng.integers(29, 61)))
+        elif k == 2:
+            cells[1] = rnd(60)                                   # 2 + 60 + 2 = 64: the limit itself
+        else:
+            cells[1] = rnd(29)                                   # 33 bytes: the first width past the packed row
+        n_wide += len(cells[1]) > 28
+        lines[i] = ",".join(cells) + "\n"
+    assert n_wide > 100
+    wide = tmp_path / "wide.csv"
+    wide.write_text("".join(lines))
+    kw = dict(fastq_fns=fns, putative_bc_csv=str(wide), whitelsit_csv=pw, max_ed=2, batchsize=200, restrand=True)
+    for dbr in (1 << 16, 400):                                   # all wide rows in one chunk / chunks with and without them
+        out_n, out_p = str(tmp_path / f"n{dbr}.fastq"), str(tmp_path / f"p{dbr}.fastq")
+        got_p = ra.assign_read(fastq_out=out_p, n_process=1, host="python", device_batch_rows=dbr, **kw)
+        got_n = ra.assign_read(fastq_out=out_n, n_process=4, host="native", device_batch_rows=dbr, **kw)
+        assert tuple(map(int, got_n)) == tuple(map(int, got_p))
+        assert open(out_n, "rb").read() == open(out_p, "rb").read()
+    # 65 bytes: refused by both hosts
+    cells = lines[5].rstrip("\n").split(",")
+    cells[1], cells[3], cells[5] = rnd(61), "ACGTACGTACGT", "ACGTA"
+    lines[5] = ",".join(cells) + "\n"
+    too = tmp_path / "too_wide.csv"
+    too.write_text("".join(lines))
+    with pytest.raises(_lib.BlazeHipError, match="exceeds the device limit of 64"):
+        ra.assign_read(fastq_out=str(tmp_path / "x.fastq"), n_process=4, host="native", **{**kw, "putative_bc_csv": str(too)})
+    with pytest.raises(ValueError, match="exceeds the device limit of 64"):
+        ra.assign_read(fastq_out=str(tmp_path / "y.fastq"), n_process=1, host="python", **{**kw, "putative_bc_csv": str(too)})

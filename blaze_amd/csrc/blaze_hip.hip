@@ -557,22 +557,12 @@ int bz_device_info(int device, int64_t info[8], char *arch, int arch_cap) {
     return BZ_OK;
 }
 
-int bz_create(int device, bz_handle *out) {
-    if (!out) return fail(BZ_E_ARG, "null out");
-    int n = 0;
-    HIP_TRY(hipGetDeviceCount(&n));
-    if (device < 0 || device >= n) return fail(BZ_E_HIP, "device %d not present (%d visible): no GPU, no compute", device, n);
-    HIP_TRY(hipSetDevice(device));
-    if (int rc = scratch_init(device)) return rc;
-    bz_engine *h = new bz_engine();
-    h->device = device;
-    {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, device));
-        h->n_cu = std::max(1, prop.multiProcessorCount);
-        HIP_TRY(hipFuncSetAttribute((const void *)bz::k_hist_partial, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)((bz::kHistLdsBins + 1) * sizeof(uint32_t))));
-    }
+static int create_buffers(bz_engine *h) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+    h->n_cu = std::max(1, prop.multiProcessorCount);
+    HIP_TRY(hipFuncSetAttribute((const void *)bz::k_hist_partial, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((bz::kHistLdsBins + 1) * sizeof(uint32_t))));
     for (Slot &s : h->slot) {
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         for (hipEvent_t &e : s.ev) HIP_TRY(hipEventCreate(&e));
@@ -586,6 +576,24 @@ int bz_create(int device, bz_handle *out) {
     HIP_TRY(hipMalloc(&h->d_pair, 4096));
     HIP_TRY(hipMalloc(&h->d_pair_out, 2 * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&h->d_f64, 64 * sizeof(double)));
+    return BZ_OK;
+}
+
+int bz_create(int device, bz_handle *out) {
+    if (!out) return fail(BZ_E_ARG, "null out");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(BZ_E_HIP, "device %d not present (%d visible): no GPU, no compute", device, n);
+    HIP_TRY(hipSetDevice(device));
+    if (int rc = scratch_init(device)) return rc;
+    bz_engine *h = new bz_engine();
+    h->device = device;
+    if (int rc = create_buffers(h)) {                 // what was made so far goes again; the message of the failed call stays
+        const std::string why = g_err;
+        bz_destroy(h);
+        g_err = why;
+        return rc;
+    }
     *out = h;
     return BZ_OK;
 }
@@ -1578,9 +1586,10 @@ int bz_valu_peak_probe(bz_handle h, int iters, double *lane_ops_per_s, float *ms
     HIP_TRY(hipGetDeviceProperties(&p, h->device));
     const int blocks = p.multiProcessorCount * 8, threads = 256;
     uint32_t *d = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct Cleanup { uint32_t *&d; hipEvent_t &e0, &e1; ~Cleanup() { if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); hipFree(d); } } cleanup{d, e0, e1};
     HIP_TRY(hipMalloc(&d, (size_t)blocks * threads * 4));
     hipStream_t st = h->slot[0].stream;
-    hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     hipLaunchKernelGGL(bz::k_valu_probe, dim3(blocks), dim3(threads), 0, st, d, iters / 8 + 1, 1u);   // warm-up
     HIP_TRY(hipEventRecord(e0, st));
@@ -1589,7 +1598,6 @@ int bz_valu_peak_probe(bz_handle h, int iters, double *lane_ops_per_s, float *ms
     HIP_TRY(hipStreamSynchronize(st));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(d);
     *lane_ops_per_s = (double)blocks * threads * (double)iters * bz::kProbeOpsPerIter / (ms * 1e-3);
     if (ms_out) *ms_out = ms;
     return BZ_OK;

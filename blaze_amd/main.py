@@ -10,7 +10,7 @@
     stage 3  main.py:410-416   read_assignment.assign_read -> demultiplexed FASTQ, two summary lines
 
 Files written, their names and their bytes are the reference's (the .gz output up to the gzip
-container, F9); the knee plot (main.py:286-302, matplotlib) is not drawn.  Every stage needs the
+container, F9), the knee plot of stage 2 included (whitelisting.knee_plot).  Every stage needs the
 GPU library: there is no CPU search / scoring path behind these functions.
 """
 from __future__ import annotations
@@ -160,6 +160,15 @@ def main(args, devices=None, host="native", comm=None):
     multi = comm is not None and comm.world > 1
     if multi and comm.rank != 0:
         return _main_worker_rank(args, devices, comm)
+    plot_threads = []                                 # the knee plot is drawn while stage 3 runs
+    try:
+        _main_rank0(args, devices, host, comm, multi, plot_threads)
+    finally:
+        for t in plot_threads:
+            t.join()
+
+
+def _main_rank0(args, devices, host, comm, multi, plot_threads):
     if args.do_bc_search:
         logger.info(f'Getting putative barcodes from {len(args.fastq_fns)} FASTQ files...')
         raw_bc_pass_count = search_putative_bc(args, devices, host, comm)
@@ -169,7 +178,8 @@ def main(args, devices=None, host="native", comm=None):
     if args.do_whitelisting:
         raw_bc_count = count_high_quality_bc(args)
         try:
-            bc_whitelist, ept_bc = whitelisting.get_bc_whitelist(raw_bc_count, args=args, engine=_engines(devices)[0])
+            bc_whitelist, ept_bc = whitelisting.get_bc_whitelist(raw_bc_count, args=args, engine=_engines(devices)[0],
+                                                                  plot_threads=plot_threads)
             with open(args.out_whitelist_fn, 'w') as f:
                 for k in bc_whitelist.keys():
                     f.write(k + '\n')

@@ -10,8 +10,9 @@ What changed underneath: the loop of :248-255 / :273-280,
 (candidates x cells third-party `edit_distance` calls from Python) is one device launch per block of
 candidates (bz_far_from_all, blaze_amd/csrc/scan_kernels.h:k_far_from_all); the order of the
 candidates, the `>` in the stop rule (2001 barcodes come out, as in test/expect_output/test_emtpy_bc_list.csv)
-and everything around the loop are kept.  The knee plot (:286-302, matplotlib) is not drawn: `out_plot_fn` is
-accepted and ignored.  No CPU scoring path: without libblaze_hip.so and a GPU the empty-drop list raises.
+and everything around the loop are kept, the knee plot (:286-302) included where matplotlib is installed (a host
+without it gets a warning instead of the picture).  No CPU scoring path: without libblaze_hip.so and a GPU the
+empty-drop list raises.
 """
 from __future__ import annotations
 
@@ -72,10 +73,52 @@ def empty_drop_list(candidates, cells, engine=None, min_ed=DEFAULT_EMPTY_DROP_MI
     return ept_bc
 
 
+def knee_plot(counts, threshold=None, out_fn='knee_plot.png'):
+    """Barcode rank plot of the high-quality putative barcode counts with the cell-calling threshold (main.py:286-302):
+    counts in descending order on log-log axes, the threshold as a dashed red line, 8 x 8 inches.  Drawn through
+    matplotlib's object interface on an Agg canvas (no pyplot state), so it may run on a thread of its own."""
+    try:
+        from matplotlib.backends.backend_agg import FigureCanvasAgg
+        from matplotlib.figure import Figure
+    except ImportError:
+        logger.warning(helper.warning_msg(f"matplotlib is not installed: the knee plot `{out_fn}` is not drawn."))
+        return
+    ranked = sorted(counts, reverse=True)
+    fig = Figure(figsize=(8, 8))
+    FigureCanvasAgg(fig)
+    ax = fig.add_subplot()
+    ax.set_title('Barcode rank plot (from high-quality putative BC)')
+    ax.loglog(ranked, marker='o', linestyle="", alpha=1, markersize=6)
+    ax.set_xlabel('Barcodes')
+    ax.set_ylabel('Read counts')
+    ax.axhline(y=threshold, color='r', linestyle='--', label='cell calling threshold')
+    ax.legend()
+    fig.savefig(out_fn)
+
+
+def _start_knee_plot(counts, threshold, out_fn, plot_threads):
+    """The plot now, or -- when the caller collects threads -- on a thread the caller joins (main.main: the picture is
+    not an input of stage 3, and rendering 10^5 markers takes as long as the rest of a small job)."""
+    if plot_threads is None:
+        knee_plot(counts, threshold, out_fn)
+        return
+    import threading
+
+    def run():
+        try:
+            knee_plot(counts, threshold, out_fn)
+        except Exception as e:        # noqa: BLE001  (a thread cannot raise into its caller: say it)
+            logger.exception(e)
+    t = threading.Thread(target=run, name="knee_plot")
+    t.start()
+    plot_threads.append(t)
+
+
 def get_bc_whitelist(raw_bc_count, full_bc_whitelist=None, exp_cells=None, count_t=None, force_cell_n=None,
                      high_sensitivity_mode=False, output_empty=True, empty_max_count=np.inf,
-                     out_plot_fn='knee_plot.png', args=None, engine=None):
-    """Cell barcodes {barcode: count} and the empty-droplet barcode list, as the reference's function of the same name."""
+                     out_plot_fn='knee_plot.png', args=None, engine=None, plot_threads=None):
+    """Cell barcodes {barcode: count} and the empty-droplet barcode list, as the reference's function of the same name.
+    `plot_threads`: a list -> the knee plot is drawn on a thread appended to it (join it before reading the picture)."""
     if args:
         full_bc_whitelist = args.full_bc_whitelist
         exp_cells = args.expect_cells
@@ -111,9 +154,11 @@ def get_bc_whitelist(raw_bc_count, full_bc_whitelist=None, exp_cells=None, count
         else:
             count_t = sorted(list(raw_bc_count.values()))[-force_cell_n]
     if count_t is not None:
+        _start_knee_plot(list(raw_bc_count.values()), count_t, out_plot_fn, plot_threads)
         cells_bc = {k: v for k, v in raw_bc_count.items() if v >= count_t}
     elif exp_cells:
         t = percentile_count_thres(list(raw_bc_count.values()), exp_cells)
+        _start_knee_plot(list(raw_bc_count.values()), t, out_plot_fn, plot_threads)
         cells_bc = {k: v for k, v in raw_bc_count.items() if v > t}
     else:
         raise ValueError('Invalid value of count_t and/or exp_cells.')

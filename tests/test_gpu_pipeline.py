@@ -64,6 +64,8 @@ def test_pipeline_files_match_the_reference(tmp_path, case, host):
     got = _read_outputs(args)
     for key, expect in case["expect"].items():
         assert got[key] == expect, f"{case['name']} / {host}: {key} differs"
+    with open(args.out_plot_fn, "rb") as h:                     # the knee plot of stage 2 (main.py:286-302)
+        assert h.read(8) == b"\x89PNG\r\n\x1a\n"
 
 
 def test_stage_gating_follows_the_namespace(tmp_path):

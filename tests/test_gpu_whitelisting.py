@@ -20,7 +20,7 @@ def test_get_bc_whitelist_golden(tmp_path, engine):
     for c in g["cases"]:
         raw = {k: v for k, v in g["raw_bc_count"][:c["n_items"]]}
         exp = c["expect"]
-        cells_bc, ept = whitelisting.get_bc_whitelist(raw, full_bc_whitelist=str(wl), engine=engine, **c["kw"])
+        cells_bc, ept = whitelisting.get_bc_whitelist(raw, full_bc_whitelist=str(wl), engine=engine, out_plot_fn=str(tmp_path / "knee.png"), **c["kw"])
         assert [[k, int(v)] for k, v in cells_bc.items()] == exp["cells_bc"], c["name"]
         assert list(ept) == exp["ept_bc"], c["name"]
 

@@ -38,12 +38,14 @@ def test_counts_and_cell_calling(tmp_path, case):
     full.write_text("".join(b + "\n" for b in case["full_whitelist"]))
     args = SimpleNamespace(out_raw_bc_fn=str(csv), minQ=a["minQ"], full_bc_whitelist=str(full), expect_cells=a["expect_cells"],
                            count_threshold=a["count_threshold"], high_sensitivity_mode=a["high_sensitivity_mode"],
-                           out_plot_fn="unused.png", empty_max_count=float("inf"), force_cells=a["force_cells"],
+                           out_plot_fn=str(tmp_path / "knee_plot.png"), empty_max_count=float("inf"), force_cells=a["force_cells"],
                            do_empty_drops_output=False)       # the empty-drop test needs the device: covered in -m gpu
     counts = bmain.count_high_quality_bc(args)
     cells, ept = whitelisting.get_bc_whitelist(counts, args=args)
     assert ept == []
     assert "".join(k + "\n" for k in cells) == case["expect"]["out_whitelist_fn"]
+    png = (tmp_path / "knee_plot.png").read_bytes()            # main.py:286-302: an 8 x 8 inch figure at the default 100 dpi
+    assert png[:8] == b"\x89PNG\r\n\x1a\n" and int.from_bytes(png[16:20], "big") == 800 == int.from_bytes(png[20:24], "big")
 
 
 def _reference_count(fn, min_q, chunk):

@@ -97,6 +97,10 @@ def main():
                         "stage1_reads_per_s": n / (t1 - t0), "stage3_reads_per_s": n / (t3 - t2), "pipeline_reads_per_s": n / (t3 - t0),
                         "stage1_input_GB_per_s": fq_bytes / (t1 - t0) / 1e9,
                         "cells_called": sum(1 for _ in open(a.out_whitelist_fn)), "summary_tail": open(a.summary_fn).read()[-90:]}
+        a = ns("all_")                                  # the three stages in ONE call: the knee plot of stage 2 is drawn while stage 3 runs
+        t0 = time.time()
+        bmain.main(a)
+        out["one_call"] = {"total_s": time.time() - t0, "pipeline_reads_per_s": n / (time.time() - t0)}
         if "--python-stage1-too" in sys.argv:
             m = min(n, 20_000)
             sub = os.path.join(d, "sub.fastq")

@@ -48,3 +48,26 @@ def test_random_cases(engine, oracle, first_seed):
         engine.set_option(_lib.BZ_OPT_TIE_RULE, 0)
         engine.set_option(_lib.BZ_OPT_SHORTCUT, 1)
     assert len(seen) > 30                                  # the draw does spread over the options
+
+
+def test_random_pipeline_jobs(tmp_path):
+    """The three stages over drawn FASTQ files and settings (tools/fuzz_pipeline.py's generator, fixed seeds): the native
+    host and the pandas host of blaze_amd.main.main write the same five files, or stop with the same exception."""
+    spec = importlib.util.spec_from_file_location("fuzz_pipeline", os.path.join(ROOT, "tools", "fuzz_pipeline.py"))
+    fp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fp)
+    modes = set()
+    for seed in range(7000, 7016):
+        d = tmp_path / str(seed)
+        d.mkdir()
+        ns, shown, _ = fp.draw_job(np.random.default_rng(seed), str(d))
+        a_n, a_p = ns("native_"), ns("pandas_")
+        e_n, e_p = fp.run(a_n, "native"), fp.run(a_p, "python")
+        assert e_n == e_p, (seed, shown)
+        o_n, o_p = fp.outputs(a_n), fp.outputs(a_p)
+        for key in o_n:
+            if e_n and key == "output_fastq":
+                continue
+            assert o_n[key] == o_p[key], (seed, shown, key)
+        modes.add((shown["kit_version"], shown["gz"], shown["batch_size"]))
+    assert len(modes) > 8

@@ -247,6 +247,36 @@ class _ThreadComm:
         return out
 
 
+def _run_sharded(fns, out, kw, world, locate, threads=4):
+    """dist.assign_read_sharded with `world` ranks as threads of this process (one GPU: the device section is serialised).
+    kw: putative_bc_csv, whitelsit_csv, max_ed, batchsize, restrand.  Returns {rank: (assigned, total)}."""
+    import threading
+    from blaze_amd import dist
+    shared = {"bar": threading.Barrier(world), "lock": threading.Lock()}
+    device_lock = threading.Lock()
+    native = dist.native_run_rank(kw["putative_bc_csv"], kw["whitelsit_csv"], kw["max_ed"], threads, kw["batchsize"], kw["restrand"], 0)
+
+    def run_rank(files, part, skip, csv_byte_offset=None):
+        with device_lock:
+            return native(files, part, skip, csv_byte_offset=csv_byte_offset)
+    run_rank.takes_byte_offset = locate            # True: every rank finds its first row in the table; False: reads are counted
+    res, errs = {}, []
+
+    def rank_main(rank):
+        try:
+            res[rank] = dist.assign_read_sharded(_ThreadComm(rank, world, shared), fns, out, n_process=threads, device=0, run_rank=run_rank, **kw)
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+            shared["bar"].abort()
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t_ in ts:
+        t_.start()
+    for t_ in ts:
+        t_.join(300)
+    assert not errs, errs
+    return res
+
+
 @pytest.mark.parametrize("locate", [True, False], ids=["located_row", "counted_reads"])
 @pytest.mark.parametrize("gz", [False, True])
 def test_file_shards_concatenate_to_the_single_run(tmp_path, gz, locate):
@@ -264,28 +294,7 @@ def test_file_shards_concatenate_to_the_single_run(tmp_path, gz, locate):
     assert per_file == [hi - lo for lo, hi in zip(bounds[:-1], bounds[1:])]          # incl. the gzipped one
     world = 3
     out = str(tmp_path / ("sharded" + suffix))
-    shared = {"bar": threading.Barrier(world), "lock": threading.Lock()}
-    device_lock = threading.Lock()
-    native = dist.native_run_rank(pc, pw, 2, 4, 300, True, 0)
-
-    def run_rank(files, part, skip, csv_byte_offset=None):
-        with device_lock:
-            return native(files, part, skip, csv_byte_offset=csv_byte_offset)
-    run_rank.takes_byte_offset = locate            # True: every rank finds its first row in the table; False: reads are counted
-    res, errs = {}, []
-
-    def rank_main(rank):
-        try:
-            res[rank] = dist.assign_read_sharded(_ThreadComm(rank, world, shared), fns, out, n_process=4, device=0, run_rank=run_rank, **kw)
-        except BaseException as e:      # noqa: BLE001
-            errs.append(e)
-            shared["bar"].abort()
-    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
-    for t_ in ts:
-        t_.start()
-    for t_ in ts:
-        t_.join(300)
-    assert not errs, errs
+    res = _run_sharded(fns, out, kw, world, locate)
     assert all(res[r] == (int(demul), int(total)) for r in range(world)) and int(total) == n
     d, t = res[0]
     assert (d, t) == (int(demul), int(total)) and t == n

@@ -1,6 +1,7 @@
 """Randomised run of step 3 over FILES on the GPU box: the native host (bz_assign_files) against the pandas host that
 mirrors the reference's loop, on freshly drawn inputs (tests/test_gpu_native_host.py's generator with its csv / FASTQ
-quirks, in three cases of ten with barcode cells wider than the packed row) and drawn --batch-size, device batch, threads, file count, CRLF, gz, restrand, max_ed.  Same bytes (decompressed
+quirks, in three cases of ten with barcode cells wider than the packed row) and drawn --batch-size, device batch, threads, file count, CRLF, gz, restrand, max_ed; three cases of five run a second time sharded by file over 2-4 ranks
+(dist.assign_read_sharded, ranks as threads).  Same bytes (decompressed
 for .gz), same counts, same gzip member count, or exit code 1.
 
 usage: python tools/fuzz_files.py [seconds] [first_seed]
@@ -25,7 +26,7 @@ def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     t_end = time.time() + seconds
-    n_cases = n_fail = n_reads = 0
+    n_cases = n_fail = n_reads = n_sharded = 0
     last = time.time()
     while time.time() < t_end:
         rng = np.random.default_rng(seed)
@@ -34,7 +35,7 @@ def main():
                  batchsize=int(rng.choice([1, 7, 64, 333, 1000, 5000])), device_batch_rows=int(rng.choice([1, 100, 700, 1 << 16])),
                  threads=int(rng.choice([1, 3, 8, 16])), n_files=int(rng.integers(1, 7)), err=float(rng.choice([0.5, 2.0, 5.0])),
                  umi_len=int(rng.choice([10, 12])), max_ed=int(rng.choice([0, 1, 2, 2, 3])), float_polyT=bool(rng.random() < 0.5),
-                 wide=bool(rng.random() < 0.3))
+                 wide=bool(rng.random() < 0.3), world=int(rng.choice([1, 1, 2, 3, 4])), locate=bool(rng.random() < 0.5))
         if p["batchsize"] == 1 and p["n"] > 1001:
             p["n"] = 999                      # pandas per one-row batch: keep the mirror's run short
         p["n_files"] = min(p["n_files"], p["n"] - 1) or 1
@@ -51,6 +52,17 @@ def main():
             ok = tuple(map(int, got_n)) == tuple(map(int, got_p)) and tg._text(out_n) == tg._text(out_p)
             if ok and p["gz"]:
                 ok = tg._gz_members(open(out_n, "rb").read()) == tg._gz_members(open(out_p, "rb").read())
+            if ok and p["world"] > 1:       # the same job sharded by file over ranks (threads here): the single run's file
+                out_s = str(tmp / ("sharded" + suffix))
+                res = tg._run_sharded(fns, out_s, {k: kw[k] for k in ("putative_bc_csv", "whitelsit_csv", "max_ed", "batchsize", "restrand")},
+                                      p["world"], p["locate"], threads=p["threads"])
+                ok = all(tuple(map(int, r)) == tuple(map(int, got_n)) for r in res.values()) and tg._text(out_s) == tg._text(out_n)
+                if ok and not p["gz"]:
+                    ok = open(out_s, "rb").read() == open(out_n, "rb").read()
+                if ok and p["gz"]:
+                    ok = tg._gz_members(open(out_s, "rb").read()) == tg._gz_members(open(out_n, "rb").read())
+                ok = ok and not [f for f in os.listdir(tmp) if ".part" in f]
+                n_sharded += 1
         n_cases += 1
         n_reads += p["n"]
         if not ok:
@@ -62,7 +74,7 @@ def main():
         if time.time() - last > 30:
             last = time.time()
             print(f"... {n_cases} cases, {n_reads} reads, {n_fail} failures", flush=True)
-    print(json.dumps({"cases": n_cases, "reads": n_reads, "failures": n_fail, "first_seed": seed0, "next_seed": seed, "seconds": seconds}), flush=True)
+    print(json.dumps({"cases": n_cases, "cases_also_run_sharded": n_sharded, "reads": n_reads, "failures": n_fail, "first_seed": seed0, "next_seed": seed, "seconds": seconds}), flush=True)
     sys.exit(1 if n_fail else 0)
 
 

@@ -138,3 +138,47 @@ def test_pipeline_two_processes_shard_the_files(tmp_path, name):
     for key, expect in case["expect"].items():
         assert got[key] == expect, f"{name}: {key} differs"
     assert not [f for f in os.listdir(tmp_path / "out") if ".part" in f]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: c["name"])
+def test_multi_rank_main_writes_the_reference_files(tmp_path, monkeypatch, case, world):
+    """main(args, comm=...) with one process per GPU: stages 1 and 3 sharded by FASTQ file, stage 2 on rank 0.  Ranks are
+    threads of this process here (one GPU: the two native file loops are serialised, everything around them -- partition,
+    parts, the all-reduces, every rank placing its part, the barriers around stage 2 -- runs as it would in processes);
+    the five files equal what the REAL reference wrote."""
+    import threading
+    from test_gpu_native_host import _ThreadComm
+    from blaze_amd import putative_bc, read_assignment
+    args = _materialise(case, str(tmp_path))
+    device_lock = threading.Lock()
+    real_s1, real_s3 = putative_bc.putative_bc_files, read_assignment._assign_files_native
+
+    def locked(fn):
+        def call(*a, **k):
+            with device_lock:
+                return fn(*a, **k)
+        return call
+    monkeypatch.setattr(putative_bc, "putative_bc_files", locked(real_s1))
+    monkeypatch.setattr(read_assignment, "_assign_files_native", locked(real_s3))
+    monkeypatch.setattr(read_assignment, "_ensure_whitelist", locked(read_assignment._ensure_whitelist))
+    read_assignment.get_engine(read_assignment._device_ids(None)[0])          # made before the threads start
+    shared = {"bar": threading.Barrier(world), "lock": threading.Lock()}
+    errs = []
+
+    def rank_main(rank):
+        try:
+            bmain.main(args, comm=_ThreadComm(rank, world, shared))
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+            shared["bar"].abort()
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not errs, errs
+    got = _read_outputs(args)
+    for key, expect in case["expect"].items():
+        assert got[key] == expect, f"{case['name']} / {world} ranks: {key} differs"
+    assert not [f for f in os.listdir(os.path.dirname(args.output_fastq)) if ".part" in f]

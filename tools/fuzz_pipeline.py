@@ -4,7 +4,8 @@ loops, on freshly drawn FASTQ files (structured reads carrying barcodes of a dra
 read ids with commas and quotes, plain and gzipped files) and drawn settings (kit, UMI length, minQ, --batch-size,
 threads, max_ed, restrand, plain / .gz output, the three cell-calling modes, high-sensitivity mode).  putative_bc.csv,
 whitelist.csv, emtpy_bc_list.csv, summary.txt and the demultiplexed FASTQ (decompressed for .gz) must be the same bytes,
-or both calls must raise the same exception type; exit code 1 otherwise.
+or both calls must raise the same exception type; two jobs of five run a third time as one process per GPU would
+(main(args, comm=...), 2-4 ranks as threads) and must write the same files again.  Exit code 1 otherwise.
 
 usage: python tools/fuzz_pipeline.py [seconds] [first_seed]
 """
@@ -19,6 +20,7 @@ from types import SimpleNamespace
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 import fuzz_stage1 as fs  # noqa: E402
@@ -116,11 +118,51 @@ def run(a, host):
         return type(e).__name__
 
 
+def run_ranks(a, world):
+    """main(args, comm=...) with `world` ranks as threads of this process (tests/test_gpu_pipeline.py does the same): the
+    native file loops and the whitelist upload are serialised on the one GPU, everything around them runs concurrently."""
+    import threading
+    from test_gpu_native_host import _ThreadComm
+    shared = {"bar": threading.Barrier(world), "lock": threading.Lock()}
+    errs = []
+
+    def rank_main(rank):
+        try:
+            bmain.main(a, comm=_ThreadComm(rank, world, shared))
+        except BaseException as e:      # noqa: BLE001
+            errs.append(type(e).__name__)
+            shared["bar"].abort()
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    real = [e for e in errs if e != "BrokenBarrierError"]
+    return (real or errs or [None])[0]
+
+
+def serialise_device_calls():
+    import threading
+    from blaze_amd import putative_bc, read_assignment
+    lock = threading.Lock()
+
+    def locked(fn):
+        def call(*a, **k):
+            with lock:
+                return fn(*a, **k)
+        return call
+    putative_bc.putative_bc_files = locked(putative_bc.putative_bc_files)
+    read_assignment._assign_files_native = locked(read_assignment._assign_files_native)
+    read_assignment._ensure_whitelist = locked(read_assignment._ensure_whitelist)
+    read_assignment.get_engine(read_assignment._device_ids(None)[0])
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    serialise_device_calls()
     seed = seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     t_end = time.time() + seconds
-    n_cases = n_fail = n_reads = n_raised = 0
+    n_cases = n_fail = n_reads = n_raised = n_ranks = 0
     last = time.time()
     while time.time() < t_end:
         rng = np.random.default_rng(seed)
@@ -135,6 +177,14 @@ def main():
                 diff.append("exception")
             elif e_n:               # both stopped: how far the output had got by then is each host's own business
                 diff = [k for k in diff if k != "output_fastq"]
+            world = int(rng.choice([1, 1, 2, 3, 4]))
+            if world > 1 and not diff and not e_n:      # the same job as one process per GPU (ranks as threads here)
+                a_r = ns("ranks_")
+                e_r = run_ranks(a_r, world)
+                o_r = outputs(a_r)
+                diff = [f"{world} ranks: {k}" for k in o_n if o_n[k] != o_r[k]] + ([f"{world} ranks raised {e_r}"] if e_r else [])
+                diff += [f for f in os.listdir(d) if ".part" in f]
+                n_ranks += 1
         n_cases += 1
         n_reads += n
         if diff:
@@ -146,7 +196,7 @@ def main():
         if time.time() - last > 30:
             last = time.time()
             print(f"... {n_cases} cases, {n_reads} reads, {n_fail} failures", flush=True)
-    print(json.dumps({"cases": n_cases, "reads": n_reads, "cases_that_raised_on_both_hosts": n_raised, "failures": n_fail, "first_seed": seed0,
+    print(json.dumps({"cases": n_cases, "reads": n_reads, "cases_that_raised_on_both_hosts": n_raised, "cases_also_run_with_2_to_4_ranks": n_ranks, "failures": n_fail, "first_seed": seed0,
                       "next_seed": seed, "seconds": seconds}), flush=True)
     sys.exit(1 if n_fail else 0)
 

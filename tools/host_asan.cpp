@@ -41,7 +41,7 @@ int main(int argc, char **argv) {
                 for (int i = 0; i < L; ++i) body.push_back((char)(33 + rng() % 60));
                 body += nl;
                 // the csv row of this read
-                std::string bc = rnd_seq(rng, rid % 31 == 0 ? 14 : 16, rid % 17 == 0), umi = rnd_seq(rng, rid % 23 == 0 ? 1 : 12, false);
+                std::string bc = rnd_seq(rng, rid % 53 == 0 ? 29 + (int)(rng() % 32) : rid % 31 == 0 ? 14 : 16, rid % 17 == 0), umi = rnd_seq(rng, rid % 23 == 0 ? 1 : 12, false);
                 std::string pre = rid % 19 == 0 ? "NA" : rid % 29 == 0 ? "" : rnd_seq(rng, 5, false), post = rid % 37 == 0 ? "null" : rnd_seq(rng, rid % 41 == 0 ? 2 : 5, false);
                 char pt[32];
                 const int L1 = L > 0 ? L : 1;
@@ -90,6 +90,10 @@ int main(int argc, char **argv) {
                 Chunk &c = *ch;
                 const int nb = (int)c.batch_start.size() - 1;
                 parallel_for(nb, job.n_threads, [&](int b) { parse_batch(c, b); });
+                if (!c.wide.empty()) {                         // barcode cells wider than the 32-byte row: the chunk again at 64
+                    widen_rows(c);
+                    for (size_t r = 0; r < n; ++r) total_out += c.ext_wide[r * kExtWide + (c.ext_len[r] ? c.ext_len[r] - 1 : 0)];
+                }
                 c.hit.resize(n); c.ed.resize(n); c.end_idx.resize(n); c.flags.resize(n);
                 for (size_t r = 0; r < n; ++r) {               // any answer the device may give
                     c.hit[r] = (int32_t)(rng() % 52) - 2;

@@ -308,7 +308,10 @@ def locate_first_row(putative_bc_csv, fastq_fns, lo, hi):
     """Where the rows of the files fastq_fns[lo:hi] start in the (plain) table, WITHOUT counting the reads of the files in
     front of them: the row whose read_id is the id of the first read of the first non-empty file (searched outward from
     where it would be if reads were spread evenly over the FASTQ bytes).  -> byte offset; 0 when those files hold no read
-    at all (nothing will be asked of the table); None when the row cannot be found (gzipped table, quoted ids)."""
+    at all (nothing will be asked of the table); None when the row cannot be found (gzipped table, quoted ids).
+    A read id that occurs twice in the job can send a rank to the earlier of its rows; the id check of the file loop
+    (read_assignment.py:219-223) then stops the job instead of writing wrong reads, and BLAZE_AMD_CSV_LOCATE=0 selects the
+    counting route, which does not depend on ids."""
     import ctypes
     from . import _lib
     rid, first = "", lo

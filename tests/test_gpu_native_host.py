@@ -213,6 +213,27 @@ def test_native_empty_inputs(tmp_path):
         assert tuple(got) == (0, 0) and out.read_bytes() == b""
 
 
+def test_empty_whitelist_file(tmp_path):
+    """whitelist.csv without a line (no cell called): every read is seen, none assigned, the output exists and is empty
+    (plain) or holds one empty member per batch (.gz), on both hosts."""
+    fns, pc, _, bounds = _make_files(tmp_path, 700, 30, seed=3, n_files=2)
+    pw = tmp_path / "none.csv"
+    pw.write_text("")
+    for suffix in (".fastq", ".fastq.gz"):
+        outs = {}
+        for host in ("native", "python"):
+            out = tmp_path / (host + suffix)
+            got = ra.assign_read(fastq_fns=fns, fastq_out=str(out), putative_bc_csv=pc, whitelsit_csv=str(pw), max_ed=2,
+                                 n_process=4, batchsize=100, host=host)
+            assert tuple(map(int, got)) == (0, 700)
+            outs[host] = out.read_bytes()
+            assert _text(str(out)) == b""
+        if suffix.endswith(".gz"):
+            assert _gz_members(outs["native"]) == _gz_members(outs["python"]) == sum(-(-(hi - lo) // 100) for lo, hi in zip(bounds[:-1], bounds[1:]))
+        else:
+            assert outs["native"] == outs["python"] == b""
+
+
 def test_native_configs3_shape_10nt_umi(tmp_path):
     """BASELINE configs[2]/[4] row shape: 10-nt UMI kits (3v2 / 5v2)."""
     fns, pc, pw, _ = _make_files(tmp_path, 3000, 800, seed=9, umi_len=10, n_files=2)

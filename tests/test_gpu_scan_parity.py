@@ -488,6 +488,9 @@ def test_empty_and_tiny_batches(engine, oracle):
         _compare(engine, oracle, ext[:n], el[:n], bo[:n], bl[:n], wl_list, 2)
     _compare(engine, oracle, ext, el, bo, bl, wl_list[:1], 2)
     _compare(engine, oracle, ext, el, bo, bl, wl_list[:3], 2)
+    for max_ed in (0, 2, 5, 9):                   # an empty whitelist (no cell called): the reference's loop has nothing to walk
+        _compare(engine, oracle, ext, el, bo, bl, [], max_ed)
+    assert (engine.assign(ext, el, bo, bl, 2)[0] == -1).all()
 
 
 def test_counts_histogram(engine, oracle):

@@ -74,6 +74,30 @@ def test_stage1_empty_batch_and_bad_input(tie_engine):
         putative_bc.search(tie_engine, ["ACGT"], ["II"], "3v3", 12)
 
 
+@pytest.mark.parametrize("kit", ["3v3", "5v2"])
+def test_stage1_empty_and_tiny_reads(tie_engine, oracle, tmp_path, kit):
+    """Reads of 0, 1, 3 ... nt (an empty sequence line is legal FASTQ): pass code 1, as the oracle's restatement, through the
+    batch call and through the file loop, mixed with a read that does carry a barcode."""
+    from oracle import stage1
+    good = "ACGTTGCA" * 3 + "CTACACGACGCTCTTCCGATCT" + "ACGTACGTACGTACGT" + "ACGTACGTACGT" + ("TTTCTTATATGGG" if kit == "5v2" else "T" * 25) + "GATTACA" * 20
+    seqs = ["", "A", "TTT", "T" * 30, good, "", "ACGTACGTACGTACGTACGT"]
+    quals = ["I" * len(s) for s in seqs]
+    code, strand, start, minq, polyt = putative_bc.search(tie_engine, seqs, quals, kit, 12)
+    for i, (s, q) in enumerate(zip(seqs, quals)):
+        o = stage1.read_stage1(s, q, kit, 12, 0)
+        assert code[i] == o["pass_code"], (i, s)
+        if o["pass_code"] == 0:
+            assert (chr(strand[i]), start[i], minq[i], polyt[i]) == (o["strand"], o["raw_bc_start"], o["raw_bc_min_q"], o["polyT_end"])
+    assert list(code) == [1, 1, 1, 1, 0, 1, 1]
+    fq = tmp_path / "tiny.fastq"
+    fq.write_text("".join(f"@t{i} x\n{s}\n+\n{q}\n" for i, (s, q) in enumerate(zip(seqs, quals))))
+    out = tmp_path / "tiny.csv"
+    counts = putative_bc.putative_bc_files([tie_engine], [str(fq)], str(out), kit=kit, umi_len=12, batch_size=3)
+    assert counts == {0: 1, 1: 6}
+    rows = out.read_text().splitlines()
+    assert len(rows) == 8 and rows[1] == "t0,,,,,," and rows[5].startswith("t4,ACGTACGTACGTACGT,")
+
+
 def _write_fastq(path, reads, gz=False):
     import gzip
     text = "".join(f"@{rid} runid=abc\n{seq}\n+\n{q}\n" for rid, seq, q in reads)

@@ -32,6 +32,11 @@ class BlazeHipError(RuntimeError):
     """A negative status from the C ABI (map to RuntimeError)."""
 
 
+class BlazeFileNotFoundError(BlazeHipError, FileNotFoundError):
+    """The native file loops could not open an input or the output: also a FileNotFoundError, which is what the
+    reference's own `open()` calls raise for the same paths (read_assignment.py:149-153, :279; main.py:311-315)."""
+
+
 _lib = None
 
 
@@ -100,5 +105,8 @@ def load():
 def check(rc: int) -> int:
     if rc < 0:
         msg = load().bz_last_error()
-        raise BlazeHipError(f"libblaze_hip status {rc}: {msg.decode(errors='replace') if msg else ''}")
+        text = msg.decode(errors='replace') if msg else ''
+        if text.startswith(("cannot open ", "cannot map ")):
+            raise BlazeFileNotFoundError(f"libblaze_hip status {rc}: {text}")
+        raise BlazeHipError(f"libblaze_hip status {rc}: {text}")
     return rc

@@ -192,9 +192,12 @@ def test_native_host_errors(tmp_path):
     short.write_text("".join(lines[:200]))
     with pytest.raises(_lib.BlazeHipError):
         ra.assign_read(putative_bc_csv=str(short), **kw)
-    # missing FASTQ
-    with pytest.raises(_lib.BlazeHipError):
-        ra.assign_read(putative_bc_csv=pc, **{**kw, "fastq_fns": [str(tmp_path / "nope.fastq")]})
+    # missing FASTQ / table / output directory: a BlazeHipError that is also the FileNotFoundError the reference's open() raises
+    for bad in ({"fastq_fns": [str(tmp_path / "nope.fastq")]}, {"putative_bc_csv": str(tmp_path / "nope.csv")},
+                {"fastq_out": str(tmp_path / "no_such_dir" / "o.fastq")}):
+        with pytest.raises(_lib.BlazeHipError) as ei:
+            ra.assign_read(**{**dict(putative_bc_csv=pc), **kw, **bad})
+        assert isinstance(ei.value, FileNotFoundError), bad
     # and the engine still works afterwards
     assert ra.assign_read(putative_bc_csv=pc, **kw)[1] == 400
 

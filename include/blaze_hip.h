@@ -90,7 +90,8 @@ int bz_device_info(int device, int64_t info[8], char *arch, int arch_cap);
 
 /* ---- engine ---------------------------------------------------------------------------- */
 /* One engine per (process, GPU).  Replaces helper.multiprocessing_submit's worker pool
- * (helper.py:135-139): the device, two streams and their staging buffers live here. */
+ * (helper.py:135-139): the device, two streams and their staging buffers live here.  A bz_create that fails part way
+ * gives back what it had made; *out is written on success only. */
 int bz_create(int device, bz_handle *out);
 int bz_destroy(bz_handle h);
 int bz_set_option(bz_handle h, int option, int64_t value);
@@ -121,7 +122,8 @@ int bz_assign_submit(bz_handle h, int slot, const uint8_t *ext, int ext_stride, 
 int bz_assign_wait(bz_handle h, int slot, int32_t *hit, int8_t *ed, int8_t *end_idx, uint8_t *flags);
 
 /* Pinned (page-locked) host memory for callers that want the boundary at PCIe speed: bz_assign_submit copies pageable
- * arrays into the engine's pinned staging first (one extra pass over every byte on the host); rows and results that
+ * arrays into the engine's pinned staging first (one extra pass over every byte on the host, shared among a few copy
+ * threads of the library when the batch is large); rows and results that
  * already live in pinned memory -- bz_host_alloc, or the caller's own hipHostRegister -- are DMA'd straight from / into
  * the caller's arrays by bz_assign_submit_pinned.  It checks that all eight arrays are pinned (BZ_E_ARG otherwise); the
  * result arrays are given at submit time and are complete when bz_assign_wait(h, slot, NULL, NULL, NULL, NULL) returns.

@@ -227,3 +227,20 @@ def test_host_parse_and_format_under_address_sanitizer(tmp_path):
         r = subprocess.run([exe, str(tmp_path / f"d{prefetch}")], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
         assert "bytes formatted" in r.stdout
+
+
+def test_file_errors_are_also_file_not_found():
+    """An input / output path the native loops cannot open: BlazeHipError for callers of this package, FileNotFoundError for
+    callers written against the reference's open() calls (read_assignment.py:149-153, :279)."""
+    from blaze_amd import _lib
+    assert issubclass(_lib.BlazeFileNotFoundError, _lib.BlazeHipError) and issubclass(_lib.BlazeFileNotFoundError, FileNotFoundError)
+    L = _lib.load()
+    n = __import__("ctypes").c_int64(0)
+    rc = L.bz_fastq_count_reads(b"/no/such/dir/reads.fastq", __import__("ctypes").byref(n))       # host-only entry point
+    assert rc < 0
+    try:
+        _lib.check(rc)
+    except FileNotFoundError as e:
+        assert isinstance(e, RuntimeError) and "cannot open" in str(e)
+    else:
+        raise AssertionError("no exception")

@@ -667,3 +667,43 @@ def test_whitelist_with_hundreds_of_irregular_entries(engine, oracle, max_ed):
         _compare(engine, oracle, ext, el, bo, bl, wl_list, max_ed, tie)
     t = engine.timing(0)
     assert t["rows_bitparallel"] > 500 and t["rows_generic"] == 0 and t["rows_mixed_fix"] > 100
+
+
+@pytest.mark.parametrize("stride", [64, 61])
+@pytest.mark.parametrize("mixed", [False, True], ids=["regular_list", "mixed_list"])
+@pytest.mark.parametrize("max_ed", [0, 2, 3, 5])
+def test_rows_up_to_the_device_limit(engine, oracle, max_ed, mixed, stride):
+    """Extensions of 33..64 bytes (BZ_EXT_MAX; what the file hosts send for barcode cells of up to 60 nt): texts longer
+    than the 32 columns the bit-parallel form of the workgroup scan holds, with a cell barcode verbatim or a few edits
+    away somewhere inside, N / lower case in places, barcode offsets 0..2 -- against the oracle, packed (64) and byte-wise
+    (61) row layout."""
+    rng = np.random.default_rng(1000 + max_ed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    wl_list = list(dict.fromkeys(bytes(acgt[rng.integers(0, 4, 16)]) for _ in range(300)))
+    if mixed:
+        wl_list.insert(5, wl_list[2][:15])
+        wl_list.insert(40, wl_list[20] + b"ACG")
+        wl_list.append(wl_list[9].lower())
+        wl_list.insert(60, b"")
+    n = 1500
+    ext = np.zeros((n, stride), np.uint8); el = np.zeros(n, np.uint8); bo = np.zeros(n, np.uint8); bl = np.zeros(n, np.uint8)
+    for r in range(n):
+        L = int(rng.integers(33, stride + 1)) if r % 7 else int(rng.integers(20, 33))
+        row = acgt[rng.integers(0, 4, L)].copy()
+        k = r % 5
+        if k != 4:                                   # plant a cell barcode (or an irregular entry), k edits away
+            w = np.frombuffer(wl_list[int(rng.integers(0, len(wl_list)))] or b"A", dtype=np.uint8).copy()
+            for _ in range(k if k < 3 else 0):
+                w[rng.integers(0, w.size)] = acgt[rng.integers(0, 4)]
+            at = int(rng.integers(0, L - w.size + 1))
+            row[at:at + w.size] = w
+        if r % 11 == 0:
+            row[rng.integers(0, L)] = ord("N")
+        if r % 13 == 0:
+            row[rng.integers(0, L)] |= 0x20
+        off = int(rng.integers(0, 3))
+        umi = int(rng.integers(0, 3))
+        ext[r, :L] = row; el[r] = L; bo[r] = off; bl[r] = L - off - umi
+    bl[::50] = 0                                     # blank rows in between
+    hit, ed, end, flags = _compare(engine, oracle, ext, el, bo, bl, wl_list, max_ed, tie=max_ed & 1)
+    assert (hit >= 0).sum() > 200 and engine.timing(0)["rows_generic"] > 1000

@@ -144,6 +144,27 @@ def draw_case(rng, big=False):
     params = dict(n_cells=len(wl), family=family, err=err, n_rows=n_rows, irregular_rows=bool(irregular_rows), mixed=bool(mixed),
                   max_ed=max_ed, tie=int(rng.integers(0, 2)), shortcut=bool(rng.random() < 0.8),
                   scan_mode=int(rng.choice([0, 0, 1, 2, 3, 4])), stride=int(rng.choice([20, 24, 32])))
+    # (drawn last, so that every earlier seed keeps its case) rows of 33..64 bytes, the device's limit: what the file hosts
+    # send for hand-made barcode cells of up to 60 nt; an entry of the list verbatim or a few edits away somewhere inside
+    params["wide_rows"] = bool(rng.random() < 0.15)
+    if params["wide_rows"]:
+        ext = np.concatenate([ext, np.zeros((n_rows, 32), dtype=np.uint8)], axis=1)
+        for r in np.flatnonzero(bl > 0):
+            if rng.random() > 0.25:
+                continue
+            L = int(rng.integers(33, 65))
+            row = ACGT[rng.integers(0, 4, L)].copy()
+            w = np.frombuffer(wl[int(rng.integers(0, len(wl)))], dtype=np.uint8)
+            if w.size and w.size <= L and rng.random() < 0.8:
+                w = np.frombuffer(mutate(rng, w.tobytes(), int(rng.integers(0, 4))), dtype=np.uint8)[:L]
+                at = int(rng.integers(0, L - w.size + 1))
+                row[at:at + w.size] = w
+            if rng.random() < 0.1:
+                row[rng.integers(0, L)] = ord("N")
+            off, umi = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+            ext[r, :] = 0
+            ext[r, :L] = row
+            el[r], bo[r], bl[r] = L, off, L - off - umi
     return params, wl, ext, el, bo, bl
 
 
@@ -165,7 +186,7 @@ def main():
         p, wl, ext, el, bo, bl = draw_case(rng, big)
         ext_s = np.ascontiguousarray(ext[:, :p["stride"]]) if p["stride"] >= int(el.max(initial=0)) else ext
         if ext_s is ext:
-            p["stride"] = 32
+            p["stride"] = int(ext.shape[1])
         eng.set_option(_lib.BZ_OPT_SCAN_MODE, 0 if p["scan_mode"] == 4 else p["scan_mode"])
         eng.set_option(_lib.BZ_OPT_PAIR_FUSED, int(p["scan_mode"] == 4))
         eng.set_option(_lib.BZ_OPT_TIE_RULE, p["tie"])

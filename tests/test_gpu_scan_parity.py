@@ -685,6 +685,9 @@ def test_rows_up_to_the_device_limit(engine, oracle, max_ed, mixed, stride):
         wl_list.insert(40, wl_list[20] + b"ACG")
         wl_list.append(wl_list[9].lower())
         wl_list.insert(60, b"")
+        wl_list.insert(80, wl_list[70] + wl_list[71] + b"ACGTACGT")             # 40 characters: longer than the match masks hold
+        wl_list.insert(90, (wl_list[10] + wl_list[11]) * 3)                      # 96: longer than any row (the row becomes the pattern)
+        wl_list.insert(95, wl_list[12] + wl_list[13] + wl_list[14] + wl_list[15])   # 64
     n = 1500
     ext = np.zeros((n, stride), np.uint8); el = np.zeros(n, np.uint8); bo = np.zeros(n, np.uint8); bl = np.zeros(n, np.uint8)
     for r in range(n):
@@ -692,7 +695,7 @@ def test_rows_up_to_the_device_limit(engine, oracle, max_ed, mixed, stride):
         row = acgt[rng.integers(0, 4, L)].copy()
         k = r % 5
         if k != 4:                                   # plant a cell barcode (or an irregular entry), k edits away
-            w = np.frombuffer(wl_list[int(rng.integers(0, len(wl_list)))] or b"A", dtype=np.uint8).copy()
+            w = np.frombuffer(wl_list[int(rng.integers(0, len(wl_list)))] or b"A", dtype=np.uint8)[:L].copy()   # (a longer entry: its head)
             for _ in range(k if k < 3 else 0):
                 w[rng.integers(0, w.size)] = acgt[rng.integers(0, 4)]
             at = int(rng.integers(0, L - w.size + 1))

@@ -652,8 +652,13 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
     if (int rc = use(h)) return rc;
     if (!offsets || n < 0 || (n > 0 && !bytes)) return fail(BZ_E_ARG, "bad whitelist arguments");
     if (n > (int64_t)1 << 30) return fail(BZ_E_LIMIT, "whitelist of %lld barcodes exceeds 2^30", (long long)n);
-    for (int64_t k = 0; k < n; ++k)
+    int64_t longest = 0;
+    for (int64_t k = 0; k < n; ++k) {
         if (offsets[k + 1] < offsets[k]) return fail(BZ_E_ARG, "offsets not monotone at %lld", (long long)k);
+        longest = std::max(longest, offsets[k + 1] - offsets[k]);
+        // an entry longer than the row is the TEXT of the replaced call and the end index a position inside it: int8 results
+        if (offsets[k + 1] - offsets[k] > 127) return fail(BZ_E_LIMIT, "whitelist entry %lld has %lld characters: at most 127", (long long)k, (long long)(offsets[k + 1] - offsets[k]));
+    }
     HIP_TRY(hipDeviceSynchronize());
     free_whitelist(h);
 
@@ -672,7 +677,11 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
     const int64_t nf = (int64_t)reg_pos.size();
     // (an empty entry -- a blank line of the list -- is one of the irregular entries: at distance 0 from every text and a
     // falsy hit in the reference's fold, fold_update_falsy; every scored row is then re-scored by k_fix_rows)
-    const bool regular = nf > 0 && (nf == n || (n - nf <= kMaxIrregular && n < ((int64_t)1 << 23)));   // k_fix_rows' event words: 23 bits of index at max_ed > 3
+    // k_fix_rows' event words: 23 bits of index at max_ed > 3, and 5 bits of end index -- an entry of more than kMaxFastEntry
+    // characters (the row then is the pattern and the end index a position inside the ENTRY) sends the whole list through
+    // the byte-wise scan, which holds any end index
+    constexpr int64_t kMaxFastEntry = 30;
+    const bool regular = nf > 0 && (nf == n || (n - nf <= kMaxIrregular && n < ((int64_t)1 << 23) && longest <= kMaxFastEntry));
     const bool mixed = regular && nf < n;
     // byte form (generic kernel + histogram size)
     std::vector<int64_t> off(n + 1);

@@ -710,3 +710,36 @@ def test_rows_up_to_the_device_limit(engine, oracle, max_ed, mixed, stride):
     bl[::50] = 0                                     # blank rows in between
     hit, ed, end, flags = _compare(engine, oracle, ext, el, bo, bl, wl_list, max_ed, tie=max_ed & 1)
     assert (hit >= 0).sum() > 200 and engine.timing(0)["rows_generic"] > 1000
+
+
+@pytest.mark.parametrize("longest,fast", [(25, True), (30, True), (31, False), (80, False), (127, False)])
+@pytest.mark.parametrize("max_ed", [1, 2, 5])
+def test_whitelist_entries_longer_than_the_row(engine, oracle, max_ed, longest, fast):
+    """A list line longer than the 20-column row: the ROW is then the pattern of the replaced call and the end index a
+    position inside the entry.  Up to 30 characters such entries ride beside the regular ones (k_mixed_fix / k_fix_rows);
+    a longer one sends the list through the byte-wise scan; beyond 127 the end index no longer fits the int8 result and
+    bz_set_whitelist refuses.  Rows: ordinary ones, and ones cut out of the long entry (distance 0..2 inside it)."""
+    rows, wl = _synthetic(1200, 150, err=2.0, seed=400 + longest)
+    ext, el, bo, bl = synth.pack_ext(rows)
+    wl_list = [w.tobytes() for w in wl]
+    rng = np.random.default_rng(longest)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    long_entry = bytes(acgt[rng.integers(0, 4, longest)])
+    wl_list.insert(40, long_entry)
+    wl_list.insert(90, wl_list[3] + wl_list[4][:longest - 16])            # a second one that starts with a regular entry
+    for r in range(0, ext.shape[0], 6):                                    # 20 columns out of the long entry, a few edits
+        if bl[r] == 0:
+            continue
+        at = int(rng.integers(0, longest - 20 + 1))
+        row = np.frombuffer(long_entry[at:at + 20], dtype=np.uint8).copy()
+        for _ in range(int(rng.integers(0, 3))):
+            row[rng.integers(0, 20)] = acgt[rng.integers(0, 4)]
+        ext[r, :20] = row
+    hit, ed, end, flags = _compare(engine, oracle, ext, el, bo, bl, wl_list, max_ed, tie=longest & 1)
+    assert (hit == 40).sum() > 50 and end[hit == 40].max() > 19
+    t = engine.timing(0)
+    assert (t["rows_generic"] < 50) == fast, t
+    if longest == 127:
+        with pytest.raises(_lib.BlazeHipError, match="at most 127"):
+            engine.set_whitelist(wl_list + [long_entry + b"A"])
+        engine.set_whitelist(wl_list)

@@ -127,12 +127,13 @@ def draw_case(rng, big=False):
     if mixed:
         n_odd = int(rng.integers(1, 6)) if rng.random() > 0.15 else int(rng.integers(260, 700))     # a few, or hundreds
         for _ in range(n_odd):
-            k = int(rng.integers(0, 8))
+            k = int(rng.integers(0, 10))
             base = wl[int(rng.integers(0, len(wl)))]
             if len(base) != 16:
                 continue
             new = [base[:15], base + b"AC", base[:6] + b"N" + base[7:], base.lower(), base[:12], b"",      # b"": a blank line of the list
-                   base + base[::-1] + b"ACGTAC", base * 5][k]           # 38 and 80 characters: past the match masks, past any row
+                   base + base[::-1] + b"ACGTAC", base * 5,              # 38 and 80 characters: past the match masks, past any row
+                   base + base[:9], base + base[2:]][k]                  # 25 and 30: longer than a 20-column row, still on the fast path
             pos = int(rng.integers(0, len(wl) + 1))
             if rng.random() < 0.5 and len(wl) > 1:
                 wl[wl.index(base)] = new                           # replaces its parent

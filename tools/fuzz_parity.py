@@ -96,7 +96,7 @@ def draw_case(rng, big=False):
         for r in np.flatnonzero(bl > 0):
             if rng.random() > 0.15:
                 continue
-            k = int(rng.integers(0, 9))
+            k = int(rng.integers(0, 11))
             if k == 0:
                 ext[r, rng.integers(0, 20)] = ord("N")
             elif k == 1:
@@ -122,6 +122,10 @@ def draw_case(rng, big=False):
                 w = np.frombuffer(wl[int(rng.integers(0, n_cells))], dtype=np.uint8)
                 ext[r, :] = 0; ext[r, 0] = ACGT[rng.integers(0, 4)]; ext[r, 1:17] = w; ext[r, 17:19] = ACGT[rng.integers(0, 4, 2)]
                 el[r], bo[r], bl[r] = 19, 1, 16
+            elif k == 9:                                          # the barcode further right than any host puts it (the ABI takes any offset)
+                bo[r] = int(rng.integers(3, 5)); bl[r] = 16
+            elif k == 10:                                         # a byte that is no letter at all
+                ext[r, rng.integers(0, 20)] = int(rng.choice([0, 1, 0x7F, 0x80, 0xC1, 0xFF, ord("-"), ord("*")]))
     ext[np.arange(32)[None, :] >= el[:, None]] = 0
     mixed = rng.random() < 0.3
     if mixed:
@@ -163,7 +167,7 @@ def draw_case(rng, big=False):
                 row[at:at + w.size] = w
             if rng.random() < 0.1:
                 row[rng.integers(0, L)] = ord("N")
-            off, umi = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+            off, umi = (int(rng.integers(0, 3)) if rng.random() < 0.7 else int(rng.integers(3, 12))), int(rng.integers(0, 3))
             ext[r, :] = 0
             ext[r, :L] = row
             el[r], bo[r], bl[r] = L, off, L - off - umi

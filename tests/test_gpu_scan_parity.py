@@ -332,8 +332,9 @@ def test_mixed_whitelist_keeps_the_fast_path(engine, oracle, max_ed, scan_mode):
 @pytest.mark.parametrize("max_ed", [0, 1, 2, 3])
 def test_mixed_whitelist_odd_entries(engine, oracle, max_ed, tie):
     """Irregular entries of every kind the mixed path scores differently: shorter than max_ed (within reach of EVERY text:
-    every scored row is re-scored by k_fix_rows), 1-, 3-, 17-, 20-, 32-character entries (bit-parallel), 21- and 40-character
-    ones (longer than the text: the text becomes the pattern, byte-wise), lower case and N inside; texts of 16..20 columns."""
+    every scored row is re-scored by k_fix_rows), 1-, 3-, 17-, 20-character entries (bit-parallel), 21-, 28- and 30-character
+    ones (longer than the text: the text becomes the pattern, byte-wise; 30 is the longest the fast path keeps,
+    test_whitelist_entries_longer_than_the_row), lower case and N inside; texts of 16..20 columns."""
     rows, wl = _synthetic(2500, 300, err=3.0, seed=81)
     ext, el, bo, bl = synth.pack_ext(rows)
     for r in range(ext.shape[0]):
@@ -344,7 +345,7 @@ def test_mixed_whitelist_odd_entries(engine, oracle, max_ed, tie):
     ext[np.arange(ext.shape[1])[None, :] >= el[:, None]] = 0
     wl_list = [w.tobytes() for w in wl]
     a, b, c = wl_list[10], wl_list[100], wl_list[200]
-    odd = [b"A", b"ACG", a + b"T", b"GG" + b + b"CA", (c + a)[:32], c + b"ACGTA", a + b + c[:8], a.lower(), b[:5] + b"N" + b[6:], c[:15] + b"a"]
+    odd = [b"A", b"ACG", a + b"T", b"GG" + b + b"CA", (c + a)[:30], c + b"ACGTA", (a + b)[:28], a.lower(), b[:5] + b"N" + b[6:], c[:15] + b"a"]
     if max_ed >= 2:
         odd.append(b"TC")
     rng = np.random.default_rng(4)

@@ -68,7 +68,7 @@ def test_native_end_to_end_golden(tmp_path, device_batch_rows, threads):
         assert (int(demul), int(total)) == (exp["demul"], exp["total"])
 
 
-def _make_files(tmp_path, n, n_cells, seed, *, crlf=False, float_polyT=True, quirks=True, n_files=3, err=2.0, umi_len=12, wide=False):
+def _make_files(tmp_path, n, n_cells, seed, *, crlf=False, float_polyT=True, quirks=True, n_files=3, err=2.0, umi_len=12, wide=False, odd_wl=False):
     """Synthetic step-3 inputs: FASTQ files (second one gzipped), putative_bc.csv, whitelist."""
     rng = np.random.default_rng(seed)
     full = synth.full_whitelist_codes(20_000, seed=seed + 1)
@@ -89,6 +89,12 @@ def _make_files(tmp_path, n, n_cells, seed, *, crlf=False, float_polyT=True, qui
                 seq = b_arr.tobytes().decode("ascii")
             recs[j] = (rid, seq, q)
     s = lambda m, i: m[i].tobytes().decode("ascii")
+    wl = ["".join(map(chr, w)) for w in synth.codes_to_bytes(cells)]
+    odd = []
+    if odd_wl:      # lines a hand-made --known-bc-list may hold (read_assignment.py:286-289 takes any): short, lower case, blank, repeated, long, N
+        odd = [wl[0][:15], wl[1 % len(wl)].lower(), "", wl[2 % len(wl)], wl[3 % len(wl)] + "ACGTACGTA", wl[4 % len(wl)][:6] + "N" + wl[4 % len(wl)][7:]]
+        for e in odd:
+            wl.insert(int(rng.integers(0, len(wl) + 1)), e)
     lines = [HEADER]
     for i in range(n):
         if rows["blank"][i]:
@@ -124,6 +130,10 @@ def _make_files(tmp_path, n, n_cells, seed, *, crlf=False, float_polyT=True, qui
                 pe_s = f"{pe}.7"                # int() truncates toward zero
             elif k == 10:
                 post = "null"
+            elif k == 12 and odd:               # the barcode cell IS one of the odd lines (the exact-match shortcut on it), or one edit away
+                bc = odd[int(rng.integers(0, len(odd)))] or bc
+                if rng.integers(0, 2) and len(bc) > 3:
+                    bc = bc[:2] + "ACGT"[int(rng.integers(0, 4))] + bc[3:]
             elif k == 11 and wide:              # a hand-made barcode cell wider than the 32-byte row (up to the device's 64)
                 m = int(rng.integers(17, 61))
                 bc = (bc + "".join("ACGT"[c] for c in rng.integers(0, 4, size=m)))[:m] if rng.integers(0, 2) else \
@@ -148,7 +158,6 @@ def _make_files(tmp_path, n, n_cells, seed, *, crlf=False, float_polyT=True, qui
             fn.write_bytes(body.encode())
         fns.append(str(fn))
     pw = tmp_path / "whitelist.csv"
-    wl = ["".join(map(chr, w)) for w in synth.codes_to_bytes(cells)]
     pw.write_text("".join(f"{w}-1\n" for w in wl))
     return fns, str(pc), str(pw), bounds
 

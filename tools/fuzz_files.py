@@ -1,6 +1,7 @@
 """Randomised run of step 3 over FILES on the GPU box: the native host (bz_assign_files) against the pandas host that
 mirrors the reference's loop, on freshly drawn inputs (tests/test_gpu_native_host.py's generator with its csv / FASTQ
-quirks, in three cases of ten with barcode cells wider than the packed row) and drawn --batch-size, device batch, threads, file count, CRLF, gz, restrand, max_ed; three cases of five run a second time sharded by file over 2-4 ranks
+quirks, in three cases of ten with barcode cells wider than the packed row, in three of ten with a whitelist file that
+holds short, lower-case, blank, repeated, long and N-containing lines) and drawn --batch-size, device batch, threads, file count, CRLF, gz, restrand, max_ed; three cases of five run a second time sharded by file over 2-4 ranks
 (dist.assign_read_sharded, ranks as threads).  Same bytes (decompressed
 for .gz), same counts, same gzip member count, or exit code 1.
 
@@ -35,14 +36,15 @@ def main():
                  batchsize=int(rng.choice([1, 7, 64, 333, 1000, 5000])), device_batch_rows=int(rng.choice([1, 100, 700, 1 << 16])),
                  threads=int(rng.choice([1, 3, 8, 16])), n_files=int(rng.integers(1, 7)), err=float(rng.choice([0.5, 2.0, 5.0])),
                  umi_len=int(rng.choice([10, 12])), max_ed=int(rng.choice([0, 1, 2, 2, 3])), float_polyT=bool(rng.random() < 0.5),
-                 wide=bool(rng.random() < 0.3), world=int(rng.choice([1, 1, 2, 3, 4])), locate=bool(rng.random() < 0.5))
+                 wide=bool(rng.random() < 0.3), world=int(rng.choice([1, 1, 2, 3, 4])), locate=bool(rng.random() < 0.5),
+                 odd_wl=bool(rng.random() < 0.3))
         if p["batchsize"] == 1 and p["n"] > 1001:
             p["n"] = 999                      # pandas per one-row batch: keep the mirror's run short
         p["n_files"] = min(p["n_files"], p["n"] - 1) or 1
         with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
             tmp = pathlib.Path(d)
             fns, pc, pw, bounds = tg._make_files(tmp, p["n"], p["cells"], seed=seed, crlf=p["crlf"], float_polyT=p["float_polyT"],
-                                                 n_files=p["n_files"], err=p["err"], umi_len=p["umi_len"], wide=p["wide"])
+                                                 n_files=p["n_files"], err=p["err"], umi_len=p["umi_len"], wide=p["wide"], odd_wl=p["odd_wl"])
             suffix = ".fastq.gz" if p["gz"] else ".fastq"
             out_n, out_p = str(tmp / ("native" + suffix)), str(tmp / ("pandas" + suffix))
             kw = dict(fastq_fns=fns, putative_bc_csv=pc, whitelsit_csv=pw, max_ed=p["max_ed"], batchsize=p["batchsize"],

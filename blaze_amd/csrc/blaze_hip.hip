@@ -677,10 +677,9 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
     const int64_t nf = (int64_t)reg_pos.size();
     // (an empty entry -- a blank line of the list -- is one of the irregular entries: at distance 0 from every text and a
     // falsy hit in the reference's fold, fold_update_falsy; every scored row is then re-scored by k_fix_rows)
-    // k_fix_rows' event words: 23 bits of index at max_ed > 3, and 5 bits of end index -- an entry of more than kMaxFastEntry
-    // characters (the row then is the pattern and the end index a position inside the ENTRY) sends the whole list through
-    // the byte-wise scan, which holds any end index
-    constexpr int64_t kMaxFastEntry = 30;
+    // (entries are at most 127 characters, checked above: k_fix_rows' event words hold end + 1 in 8 bits; the index bound is
+    // kept from the 32-bit event words of earlier builds)
+    constexpr int64_t kMaxFastEntry = 127;
     const bool regular = nf > 0 && (nf == n || (n - nf <= kMaxIrregular && n < ((int64_t)1 << 23) && longest <= kMaxFastEntry));
     const bool mixed = regular && nf < n;
     // byte form (generic kernel + histogram size)

@@ -1601,7 +1601,6 @@ __global__ __launch_bounds__(256) void k_pair_tail(
 // then is the pattern, as in the replaced FFI) take the byte-wise DP.  An EMPTY entry (a blank line of the list) is at
 // distance 0 from every text -- every scored row is re-scored -- and a falsy hit in the reference's fold:
 // fold_update_falsy / relevant_empties.
-constexpr int kEndNone = 31;                                      // event words hold end + 0..19, or this for "no column" (end -1)
 
 // the text of a regular row: 2-bit codes (column j at bits 2j) from its bytes
 __device__ __forceinline__ uint64_t row_codes(const RowBytes &rb, int len) {
@@ -1648,10 +1647,9 @@ __global__ __launch_bounds__(256) void k_fix_rows(
     const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
     const int32_t *__restrict__ fix_list, const int32_t *__restrict__ n_fix_ptr, int tie,
     int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
-    __shared__ uint32_t s_min[2][K + 1];
+    __shared__ unsigned long long s_min[2][K + 1];               // event word: index << 16 | ed << 8 | end + 1 (an entry longer than the row: end up to 126)
     __shared__ int s_empty;                                       // smallest index of an empty entry, or kNoIndex
-    constexpr int kEndEmpty = 30;                                 // end field of the empty entry's event (a real end is <= 19)
-    constexpr int kEdBits = K <= 3 ? 2 : 4;                       // event word: index | ed | end (5 bits); 25 / 23 bits of index (host checks)
+    constexpr unsigned long long kNoEvent = ~0ull, kEndEmpty = 255ull;   // end field of the empty entry's event (a real end + 1 is <= 127)
     const int n_fix = *n_fix_ptr;
     const int tid = threadIdx.x;
     for (int f = blockIdx.x; f < n_fix; f += gridDim.x) {         // workgroup-uniform
@@ -1667,11 +1665,11 @@ __global__ __launch_bounds__(256) void k_fix_rows(
             XL[j] = (code & 1u) ? 0u : 0xFFFFFFFFu;
         }
         const uint64_t tc = row_codes(rb, len);
-        uint32_t keep[K + 1][2];
+        unsigned long long keep[K + 1][2];
 #pragma unroll
-        for (int c = 0; c <= K; ++c) { keep[c][0] = 0xFFFFFFFFu; keep[c][1] = 0xFFFFFFFFu; }
+        for (int c = 0; c <= K; ++c) { keep[c][0] = kNoEvent; keep[c][1] = kNoEvent; }
         auto note = [&](int idx, int ed, int end) {
-            const uint32_t ev = ((uint32_t)idx << (5 + kEdBits)) | ((uint32_t)ed << 5) | (uint32_t)(end < 0 ? kEndNone : end);
+            const unsigned long long ev = ((unsigned long long)(uint32_t)idx << 16) | ((unsigned long long)ed << 8) | (unsigned long long)(end + 1);
 #pragma unroll
             for (int c = 0; c <= K; ++c) {
                 if (c != ed) continue;
@@ -1692,34 +1690,34 @@ __global__ __launch_bounds__(256) void k_fix_rows(
             irr_exact<K>(irr_peq[k], irr_meta[k].x, irr_bytes + irr_off[k], row, tc, len, tie, ed, end);
             if (ed <= K) note(irr_meta[k].y, ed, end);
         }
-        if (tid <= K) { s_min[0][tid] = 0xFFFFFFFFu; s_min[1][tid] = 0xFFFFFFFFu; }
+        if (tid <= K) { s_min[0][tid] = kNoEvent; s_min[1][tid] = kNoEvent; }
         if (tid == 0) s_empty = kNoIndex;
         __syncthreads();
         if (my_empty != kNoIndex) atomicMin(&s_empty, my_empty);
 #pragma unroll
-        for (int c = 0; c <= K; ++c) if (keep[c][0] != 0xFFFFFFFFu) atomicMin(&s_min[0][c], keep[c][0]);
+        for (int c = 0; c <= K; ++c) if (keep[c][0] != kNoEvent) atomicMin(&s_min[0][c], keep[c][0]);
         __syncthreads();
 #pragma unroll
         for (int c = 0; c <= K; ++c) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                if (keep[c][t] != 0xFFFFFFFFu && keep[c][t] != s_min[0][c]) atomicMin(&s_min[1][c], keep[c][t]);
+                if (keep[c][t] != kNoEvent && keep[c][t] != s_min[0][c]) atomicMin(&s_min[1][c], keep[c][t]);
         }
         __syncthreads();
         if (tid == 0) {
-            uint32_t ev[2 * (K + 1) + 2];
+            unsigned long long ev[2 * (K + 1) + 2];
             int nev = 0;
 #pragma unroll
             for (int c = 0; c <= K; ++c) {
-                if (s_min[0][c] != 0xFFFFFFFFu) ev[nev++] = s_min[0][c];
-                if (s_min[1][c] != 0xFFFFFFFFu) ev[nev++] = s_min[1][c];
+                if (s_min[0][c] != kNoEvent) ev[nev++] = s_min[0][c];
+                if (s_min[1][c] != kNoEvent) ev[nev++] = s_min[1][c];
             }
             int e_a, e_b;
-            relevant_empties(irr_meta, n_irr, s_empty, s_min[0][0] != 0xFFFFFFFFu ? (int)(s_min[0][0] >> (5 + kEdBits)) : kNoIndex, e_a, e_b);
-            if (e_a != kNoIndex) ev[nev++] = ((uint32_t)e_a << (5 + kEdBits)) | (uint32_t)kEndEmpty;
-            if (e_b != kNoIndex) ev[nev++] = ((uint32_t)e_b << (5 + kEdBits)) | (uint32_t)kEndEmpty;
+            relevant_empties(irr_meta, n_irr, s_empty, s_min[0][0] != kNoEvent ? (int)(s_min[0][0] >> 16) : kNoIndex, e_a, e_b);
+            if (e_a != kNoIndex) ev[nev++] = ((unsigned long long)(uint32_t)e_a << 16) | kEndEmpty;
+            if (e_b != kNoIndex) ev[nev++] = ((unsigned long long)(uint32_t)e_b << 16) | kEndEmpty;
             for (int a = 1; a < nev; ++a) {                       // whitelist order = order of the words (index in the top bits)
-                const uint32_t v = ev[a];
+                const unsigned long long v = ev[a];
                 int b = a - 1;
                 while (b >= 0 && ev[b] > v) { ev[b + 1] = ev[b]; --b; }
                 ev[b + 1] = v;
@@ -1727,9 +1725,9 @@ __global__ __launch_bounds__(256) void k_fix_rows(
             int best = K, hit = kHitNone, hit_end = -1;
             bool done = false, hit_empty = false;
             for (int a = 0; a < nev; ++a) {
-                const int e = (int)(ev[a] & 31u);
-                fold_update_falsy((int)((ev[a] >> 5) & ((1u << kEdBits) - 1u)), (e == kEndNone || e == kEndEmpty) ? -1 : e,
-                                  (int)(ev[a] >> (5 + kEdBits)), e == kEndEmpty, best, hit, hit_end, hit_empty, done);
+                const int e = (int)(ev[a] & 0xFFu);
+                fold_update_falsy((int)((ev[a] >> 8) & 0xFFu), e == (int)kEndEmpty ? -1 : e - 1,
+                                  (int)(ev[a] >> 16), e == (int)kEndEmpty, best, hit, hit_end, hit_empty, done);
             }
             const bool ok = hit >= 0 && !hit_empty;
             hit_out[r] = ok ? hit : -1;

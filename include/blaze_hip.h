@@ -103,9 +103,8 @@ int bz_set_option(bz_handle h, int option, int64_t value);
  * 16-nt ACGT entries are packed 2 bits/base into the bit-plane layout the kernels stream and get the seed indices;
  * any other line the reference would accept (read_assignment.py:286-289: other lengths, other letters, a blank line)
  * is kept as an irregular entry beside them -- up to 65,536 -- and scored exactly (same results, slower rows).  An entry
- * longer than a row is the TEXT of the replaced call and the end index a position inside it: with an entry of more than
- * 30 characters the whole list takes the byte-wise scan (same results, far slower), more than 127 is BZ_E_LIMIT (the end
- * index would not fit the int8 result). */
+ * longer than a row is the TEXT of the replaced call and the end index a position inside it: an entry of more than 127
+ * characters is BZ_E_LIMIT (the end index would not fit the int8 result). */
 int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int64_t n);
 
 /* Rows.  Row r is the extension ext[r*ext_stride .. +ext_len[r]) =

@@ -1,7 +1,7 @@
 """GPU parity on randomly drawn cases (tools/fuzz_parity.py's generator, fixed seeds): whitelists with families of
 near-identical barcodes, irregular rows and entries, every max_ed 0..5, both tie rules, shortcut on / off, every scan
 mode, three row strides -- bit-exact against the oracle.  The open-ended run of the same generator is
-`python tools/fuzz_parity.py <seconds>` (profiles/r02u_fuzz_parity.txt: 66,724 cases, 70.8 M rows; the one difference it found -- whitelist lines longer than the row, a match ending past their 30th character -- is fixed and in tests/test_gpu_scan_parity.py)."""
+`python tools/fuzz_parity.py <seconds>` (profiles/r02u_fuzz_parity.txt: 69,676 cases, 74.2 M rows; the one difference it found -- whitelist lines longer than the row, a match ending past their 30th character -- is fixed and in tests/test_gpu_scan_parity.py)."""
 import importlib.util
 import os
 

@@ -53,8 +53,8 @@ def launch_ranks(n, argv):
     run_id = uuid.uuid4().hex[:12]
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), BLAZE_AMD_RUN_ID=run_id, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), BLAZE_AMD_RUN_ID=run_id)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
     out0 = procs[0].communicate()[0]
@@ -206,6 +206,8 @@ def main():
     ap.add_argument("--no-high-error", action="store_true", help="skip the leg with SURVEY 8d's high-error reads")
     ap.add_argument("--no-files", action="store_true", help="skip the step-3-over-files leg (N=1 only)")
     ap.add_argument("--file-reads", type=int, default=500_000)
+    ap.add_argument("--allow-shared-gpu", action="store_true",
+                    help="rehearsal only: let several ranks share one physical GPU (the line then says n_gpus = distinct GPUs)")
     a = ap.parse_args()
     if a.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -220,12 +222,23 @@ def main():
                          f"that would be read as {a.gpus} GPUs\n")
         sys.exit(2)
 
-    from blaze_amd.engine import device_count
+    from blaze_amd.engine import device_count, device_identity
     stub = bool(os.environ.get("BLAZE_AMD_BENCH_ENGINE"))
     n_dev = 1 if stub else device_count()     # a launcher may narrow each rank's view to its own GPU
     device = local_rank % max(n_dev, 1)
     eng, stub = make_engine(device)
     info = {"stand-in": True} if stub else device_info(device)
+    # Which PHYSICAL GPU does every rank hold?  A local device index says nothing (a launcher that narrows visibility gives
+    # every rank "device 0"): all-gather the PCI address + UUID and count the distinct ones.  Fewer GPUs than --gpus would
+    # make the line read as a scaling point it is not: refuse, on every rank, unless this is a declared rehearsal.
+    ident = eng.device_identity() if stub else device_identity(device)
+    idents = dist.get_hub().allgather(ident) if world > 1 else [ident]
+    n_distinct = len(set(idents))
+    if n_distinct < a.gpus and not a.allow_shared_gpu:
+        if rank == 0:
+            sys.stderr.write(f"bench.py: --gpus {a.gpus} but the {world} ranks hold only {n_distinct} distinct GPU(s) {sorted(set(idents))}: "
+                             f"refusing to print a line that would be read as {a.gpus} GPUs (--allow-shared-gpu for a rehearsal)\n")
+        sys.exit(2)
     # librccl prints a version banner on stdout when it initialises: keep stdout for the one JSON line
     sys.stdout.flush()
     saved_stdout = os.dup(1)
@@ -424,7 +437,7 @@ def main():
     best_boundary = max(boundary.values())
     out = {
         "metric": "reads assigned/sec (whole node) vs 5k-cell whitelist; % int roofline",
-        "value": value, "unit": "reads/s", "n_gpus": world, "n_gpus_requested": a.gpus, "steps": a.steps, "warmup": a.warmup,
+        "value": value, "unit": "reads/s", "n_gpus": n_distinct, "n_ranks": world, "n_gpus_requested": a.gpus, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "dtype_note": "32-bit integer bit-vectors: two 16-bit automata per lane register",
         "data": "synthetic" if not stub else "STAND-IN ENGINE (launch-logic test, not a measurement)",
@@ -433,7 +446,8 @@ def main():
                    "rows_per_gpu": a.rows, "cells": a.cells, "umi_len": 12, "errors": rows["params"],
                    "parallelism": f"read-sharded x{world}, whitelist replicated", "comm": plumb.kind,
                    "launcher": "torchrun / env" if launched and "BLAZE_AMD_RUN_ID" not in os.environ else ("bench.py --gpus" if world > 1 else "single process"),
-                   "devices_visible": n_dev, "ranks_per_device": -(-world // max(n_dev, 1)), "device": info},
+                   "devices_visible": n_dev, "distinct_gpus": n_distinct, "ranks_per_gpu": max(idents.count(x) for x in set(idents)),
+                   "gpu_of_rank": idents, "shared_gpu_rehearsal": bool(n_distinct < world), "device": info},
         "assigned": assigned_total, "rows_counted": rows_total,
         "rows_scored_per_step": t_short["rows_bitparallel"], "rows_generic_per_step": t_short["rows_generic"],
         "rows_redone_per_step": t_short["rows_redo"],

@@ -24,7 +24,7 @@ EXPORTS = [
     "bz_assign_run", "bz_assign_fetch", "bz_slot_sync", "bz_slot_timing", "bz_sub_edit_distance",
     "bz_edit_distance", "bz_counts_reset", "bz_counts_get", "bz_comm_unique_id", "bz_comm_init",
     "bz_comm_allreduce_counts", "bz_comm_allreduce_f64", "bz_comm_destroy", "bz_valu_peak_probe", "bz_assign_files", "bz_far_from_all", "bz_putative_bc",
-    "bz_putative_bc_files", "bz_assign_files_from", "bz_fastq_count_reads", "bz_assign_device_noalloc", "bz_comm_allreduce_i64", "bz_host_alloc", "bz_host_free", "bz_assign_submit_pinned", "bz_gzip_fastq_bound", "bz_gzip_fastq_member", "bz_fastq_first_read_id", "bz_csv_locate_read", "bz_assign_files_at",
+    "bz_putative_bc_files", "bz_assign_files_from", "bz_fastq_count_reads", "bz_assign_device_noalloc", "bz_comm_allreduce_i64", "bz_host_alloc", "bz_host_free", "bz_assign_submit_pinned", "bz_gzip_fastq_bound", "bz_gzip_fastq_member", "bz_fastq_first_read_id", "bz_csv_locate_read", "bz_assign_files_at", "bz_device_identity",
 ]
 
 
@@ -49,6 +49,11 @@ def load():
         raise BlazeHipError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
             "blaze_amd has no CPU path.")
+    # One HSA knob, the same on every launch route (torchrun, `bench.py --gpus N`, a plain import): this pool's host
+    # driver shares device buffers between processes through dmabuf only, and RCCL's intra-node P2P transport needs
+    # that sharing (without it: `hipIpcGetMemHandle: invalid argument` at the first collective).  Set before the HIP
+    # runtime initialises (it reads the variable once); a value the user exported wins.  INTEGRATION.md section 4.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     L = ctypes.CDLL(LIB_PATH)
     i, i64, p, cp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_char_p
     pi = ctypes.POINTER(ctypes.c_int)
@@ -57,6 +62,7 @@ def load():
         "bz_last_error": ([], cp),
         "bz_device_count": ([pi], i),
         "bz_device_info": ([i, p, p, i], i),
+        "bz_device_identity": ([i, p, i], i),
         "bz_create": ([i, ctypes.POINTER(p)], i),
         "bz_destroy": ([p], i),
         "bz_set_option": ([p, i, i64], i),

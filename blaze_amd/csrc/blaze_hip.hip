@@ -575,6 +575,18 @@ int bz_device_info(int device, int64_t info[8], char *arch, int arch_cap) {
     return BZ_OK;
 }
 
+int bz_device_identity(int device, char *out, int cap) {
+    if (!out || cap < 64) return fail(BZ_E_ARG, "identity buffer of at least 64 bytes needed");
+    char bus[32] = {0};
+    HIP_TRY(hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device));
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    // PCI address + the UUID bytes as hex: two ranks that print the same string share one physical GPU
+    int k = snprintf(out, (size_t)cap, "%s/", bus);
+    for (int i = 0; i < 16 && k + 2 < cap; ++i) k += snprintf(out + k, (size_t)(cap - k), "%02x", (unsigned)(uint8_t)p.uuid.bytes[i]);
+    return BZ_OK;
+}
+
 static int create_buffers(bz_engine *h) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, h->device));

@@ -26,6 +26,25 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def local_world(comm=None) -> int:
+    """Ranks of this job on THIS node: $LOCAL_WORLD_SIZE (torchrun and `bench.py --gpus` set it), else the
+    communicator's size (ranks run as threads of one process), else $WORLD_SIZE (single-node launchers), else 1."""
+    env = os.environ.get("LOCAL_WORLD_SIZE")
+    if env:
+        return max(1, int(env))
+    if comm is not None:
+        return max(1, int(comm.world))
+    return max(1, int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def host_threads_per_rank(n_process, comm=None) -> int:
+    """The job's --threads (reference default cpu_count - 1, parser.py:64) is a budget for the HOST, as the reference's one
+    pool is (helper.py:137: min(n_process - 1, cpu_count - 1) workers): with one process per GPU every rank of the node
+    takes its share of it, not all of it -- 8 ranks x (cpu - 1) threads would oversubscribe the node 8 times."""
+    budget = max(1, min(int(n_process or 1), os.cpu_count() or 1))
+    return max(1, min(budget // local_world(comm), 256))
+
+
 class LocalComm:
     """world_size 1."""
     rank, world = 0, 1
@@ -328,9 +347,10 @@ def locate_first_row(putative_bc_csv, fastq_fns, lo, hi):
     return None if off.value < 0 else int(off.value)
 
 
-def native_run_rank(putative_bc_csv, whitelsit_csv, max_ed, n_process, batchsize, restrand=True, device=None):
+def native_run_rank(putative_bc_csv, whitelsit_csv, max_ed, n_process, batchsize, restrand=True, device=None, comm=None):
     """What one rank does with its files in assign_read_sharded: the native device pipeline (bz_assign_files_from) on this
-    process's GPU, `csv_skip_rows` rows of the table skipped.  -> run_rank(fns, out, csv_skip_rows) = (assigned, seen)."""
+    process's GPU, `csv_skip_rows` rows of the table skipped, on this rank's share of the host threads
+    (host_threads_per_rank).  -> run_rank(fns, out, csv_skip_rows) = (assigned, seen)."""
     from . import read_assignment as ra
 
     def run_rank(fns, out, csv_skip_rows, csv_byte_offset=None):
@@ -342,7 +362,8 @@ def native_run_rank(putative_bc_csv, whitelsit_csv, max_ed, n_process, batchsize
         dev = device if device is not None else ra._device_ids(None)[0]
         eng = ra.get_engine(dev)
         ra._ensure_whitelist(eng, ordered)
-        threads = max(1, min(int(n_process or 1), os.cpu_count() or 1, 256))
+        threads = host_threads_per_rank(n_process, comm)
+        run_rank.host_threads = threads
         return ra._assign_files_native([eng], fns, putative_bc_csv, out, str(out).endswith('.gz'), restrand, max_ed, batchsize,
                                        ra.DEVICE_BATCH_ROWS, threads, csv_skip_rows=csv_skip_rows or 0, csv_byte_offset=csv_byte_offset)
     run_rank.takes_byte_offset = True
@@ -366,7 +387,7 @@ def assign_read_sharded(comm, fastq_fns, fastq_out, putative_bc_csv, whitelsit_c
     if hi <= lo and os.path.exists(part):
         os.remove(part)                              # left behind by an earlier run that died: not this run's bytes
     if run_rank is None:
-        run_rank = native_run_rank(putative_bc_csv, whitelsit_csv, max_ed, n_process, batchsize, restrand, device)
+        run_rank = native_run_rank(putative_bc_csv, whitelsit_csv, max_ed, n_process, batchsize, restrand, device, comm)
     # Where do this rank's rows of the table start?  First choice: find the row of its first read in the table itself (no
     # FASTQ byte is read twice); every rank must succeed, else all fall back to counting the reads of their own files and
     # one all-reduce of the counts.
@@ -383,7 +404,7 @@ def assign_read_sharded(comm, fastq_fns, fastq_out, putative_bc_csv, whitelsit_c
     mine = np.zeros(comm.world, dtype=np.int64)
     # counting gzipped files means inflating them: the files of this rank side by side (the native counter drops the GIL)
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max(1, min(int(n_process or 1), 16, hi - lo or 1))) as pool:
+    with ThreadPoolExecutor(max(1, min(host_threads_per_rank(n_process, comm), 16, hi - lo or 1))) as pool:
         mine[comm.rank] = sum(pool.map(count_reads, fastq_fns[lo:hi]))
     per_rank = comm.allreduce_sum_i64(mine)                     # every rank's read count
     skip = int(per_rank[:comm.rank].sum())
@@ -524,7 +545,8 @@ def putative_bc_files_sharded(comm, fastq_fns, out_csv, kit, umi_len, min_q, bat
     """The stage-1 loop (main.py:344-364) with the FASTQ files sharded over the ranks of `comm`, one process per GPU:
     rank r searches its contiguous run of files into `part_path(out_csv, r)`, the pass-code counts are summed once, and
     every rank places its own part (one header kept) at its offset of `out_csv` (place_parts): the bytes of a single-process run, because
-    reference batches never span files (main.py:311-323).  Returns the GLOBAL {pass code: reads}."""
+    reference batches never span files (main.py:311-323).  `n_threads` is the HOST's budget (--threads): every rank takes its
+    share (host_threads_per_rank).  Returns the GLOBAL {pass code: reads}."""
     from . import putative_bc, read_assignment as ra
     fastq_fns = [str(f) for f in fastq_fns]
     lo, hi = partition_files([os.path.getsize(f) for f in fastq_fns], comm.world)[comm.rank]
@@ -535,7 +557,7 @@ def putative_bc_files_sharded(comm, fastq_fns, out_csv, kit, umi_len, min_q, bat
         def run_rank(fns, out):
             eng = ra.get_engine(device if device is not None else ra._device_ids(None)[0])
             return putative_bc.putative_bc_files([eng], fns, out, kit=kit, umi_len=umi_len, min_q=min_q, batch_size=batch_size,
-                                                 n_threads=n_threads)
+                                                 n_threads=host_threads_per_rank(n_threads, comm))
     counts = run_rank(fastq_fns[lo:hi], part) if hi > lo else {}
     codes = (0, 1, 2, 10, 100)
     # no reads at all: the reference never creates the table (main.py:361)

@@ -254,6 +254,13 @@ def device_count() -> int:
     return n.value
 
 
+def device_identity(device: int = 0) -> str:
+    """'<PCI bus id>/<uuid>' of a visible device: equal strings on two ranks = one physical GPU shared."""
+    buf = ctypes.create_string_buffer(128)
+    check(_lib.load().bz_device_identity(int(device), buf, 128))
+    return buf.value.decode()
+
+
 def device_info(device: int = 0) -> dict:
     info = (ctypes.c_int64 * 8)()
     arch = ctypes.create_string_buffer(64)

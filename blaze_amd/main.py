@@ -82,9 +82,8 @@ def search_putative_bc(args, devices=None, host="native", comm=None):
     counts = defaultdict(int)
     if comm is not None and comm.world > 1:
         from . import dist
-        threads = max(1, min(int(args.threads or 1), os.cpu_count() or 1, 64))
         counts.update(dist.putative_bc_files_sharded(comm, args.fastq_fns, args.out_raw_bc_fn, args.kit_version, args.umi_len,
-                                                     args.minQ, args.batch_size, threads,
+                                                     args.minQ, args.batch_size, args.threads,     # the host's budget: split per rank there
                                                      device=read_assignment._device_ids(devices)[0]))
         return counts
     if host == "native":
@@ -168,13 +167,37 @@ def main(args, devices=None, host="native", comm=None):
             t.join()
 
 
+def _agree_to_go_on(comm, failed: bool) -> bool:
+    """The collective between stage 2 (rank 0's) and stage 3 (everybody's): a sum of 'I failed' flags instead of a bare
+    barrier, so that a rank that raised still reaches it and the others leave instead of waiting for ever."""
+    import numpy as np
+    return int(comm.allreduce_sum_i64(np.array([1 if failed else 0], dtype=np.int64))[0]) == 0
+
+
 def _main_rank0(args, devices, host, comm, multi, plot_threads):
+    _search(args, devices, host, comm)               # stage 1: with several ranks a collective of its own (sharded files)
+    if not multi:
+        _whitelist(args, devices, plot_threads)
+        return _demultiplex(args, devices, host, comm, multi)
+    try:
+        _whitelist(args, devices, plot_threads)      # stage 2 and the summary are rank 0's alone
+    except BaseException:
+        _agree_to_go_on(comm, True)                  # the other ranks are waiting in this collective: tell them, then raise
+        raise
+    if not _agree_to_go_on(comm, False):             # whitelist.csv is on disk for the other ranks
+        raise RuntimeError("another rank failed before read assignment")
+    _demultiplex(args, devices, host, comm, multi)
+
+
+def _search(args, devices, host, comm):
     if args.do_bc_search:
         logger.info(f'Getting putative barcodes from {len(args.fastq_fns)} FASTQ files...')
         raw_bc_pass_count = search_putative_bc(args, devices, host, comm)
         helper.green_msg(f'Putative barcode table saved in {args.out_raw_bc_fn}', printit=True)
         add_summary(bc_search_qc_report(raw_bc_pass_count, args), args=args, write_mode='w')
 
+
+def _whitelist(args, devices, plot_threads):
     if args.do_whitelisting:
         raw_bc_count = count_high_quality_bc(args)
         try:
@@ -194,8 +217,8 @@ def _main_rank0(args, devices, host, comm, multi, plot_threads):
         else:
             helper.green_msg(f'Whitelist saved as `{args.out_whitelist_fn}`!', printit=True)
 
-    if multi:
-        comm.barrier()                                # whitelist.csv is on disk for the other ranks
+
+def _demultiplex(args, devices, host, comm, multi):
     if args.do_demultiplexing:
         logger.info("Assigning reads to whitelist.\n")
         if multi:
@@ -217,6 +240,7 @@ def _main_worker_rank(args, devices, comm):
     """Ranks > 0 of a multi-GPU run: their share of stages 1 and 3, in step with rank 0's collectives."""
     if args.do_bc_search:
         search_putative_bc(args, devices, "native", comm)
-    comm.barrier()                                    # rank 0 has written whitelist.csv (or skipped whitelisting)
+    if not _agree_to_go_on(comm, False):              # rank 0 has written whitelist.csv (or skipped whitelisting) -- or failed
+        raise SystemExit("blaze_amd: rank 0 failed before read assignment (its message is above); nothing assigned")
     if args.do_demultiplexing:
         _assign_sharded(args, devices, comm)

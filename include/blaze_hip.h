@@ -87,6 +87,10 @@ const char *bz_last_error(void);
 int bz_device_count(int *count);
 /* info[0]=compute units, [1]=max clock kHz, [2]=wavefront size, [3]=total HBM MiB, [4]=LDS bytes per CU */
 int bz_device_info(int device, int64_t info[8], char *arch, int arch_cap);
+/* "<PCI bus id>/<uuid as hex>" of a visible device (cap >= 64): what bench.py's ranks exchange to count the DISTINCT GPUs of a
+ * multi-process run -- a launcher that narrows every rank's view makes each rank see "device 0" (no reference counterpart:
+ * the reference's pool workers share the host's cores, helper.py:137). */
+int bz_device_identity(int device, char *out, int cap);
 
 /* ---- engine ---------------------------------------------------------------------------- */
 /* One engine per (process, GPU).  Replaces helper.multiprocessing_submit's worker pool

@@ -13,6 +13,13 @@ class StubEngine:
     def set_option(self, *a):
         pass
 
+    def device_identity(self):
+        """bench.py counts the distinct GPUs of a run from these: $STUB_GPU_OF_RANK = comma list, one pretend GPU per rank."""
+        import os
+        ids = os.environ.get("STUB_GPU_OF_RANK", "")
+        rank = int(os.environ.get("RANK", "0"))
+        return ids.split(",")[rank] if ids else f"stub-gpu-{rank}"
+
     def set_whitelist_codes16(self, m):
         self.n_wl = int(m.shape[0])
         self._counts = np.zeros(self.n_wl + 2, dtype=np.int64)

@@ -432,3 +432,79 @@ def test_make_comm_falls_back_to_the_hub_on_every_rank(tmp_path, who):
     script = tmp_path / "comm_worker.py"
     script.write_text(COMM_WORKER)
     _launch_two(script, who)
+
+
+def test_bench_counts_distinct_gpus_not_ranks():
+    """Two ranks that hold the SAME physical GPU (identities all-gathered over the hub) are not a 2-GPU point: refused
+    with status 2 on every rank, or -- declared a rehearsal -- printed with n_gpus = 1."""
+    import json
+    args = ["--gpus", "2", "--steps", "2", "--warmup", "0", "--rows", "2048", "--cells", "32"]
+    p = _run_bench(args, dict(STUB_GPU_OF_RANK="0000:05:00.0/aa,0000:05:00.0/aa"))
+    assert p.returncode != 0 and "1 distinct GPU" in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    p = _run_bench(args + ["--allow-shared-gpu"], dict(STUB_GPU_OF_RANK="0000:05:00.0/aa,0000:05:00.0/aa"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["n_ranks"] == 2 and out["n_gpus_requested"] == 2
+    assert out["config"]["shared_gpu_rehearsal"] is True and out["config"]["ranks_per_gpu"] == 2
+    # two different GPUs behind the same local index (a launcher that narrows every rank's view): a real 2-GPU point
+    p = _run_bench(args, dict(STUB_GPU_OF_RANK="0000:05:00.0/aa,0000:26:00.0/bb"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["config"]["shared_gpu_rehearsal"] is False and len(out["config"]["gpu_of_rank"]) == 2
+
+
+def test_host_threads_are_split_over_the_ranks_of_a_node(monkeypatch):
+    from blaze_amd import dist
+    cpus = os.cpu_count() or 1
+
+    class C:
+        world = 4
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert dist.host_threads_per_rank(cpus) == cpus                         # one process: the whole budget
+    assert dist.host_threads_per_rank(cpus, C()) == max(1, cpus // 4)        # ranks as threads of one process
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    assert dist.host_threads_per_rank(10_000) == max(1, cpus // 8)          # the reference's default cpu-1, 8 ranks per node
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")                             # 2 nodes x ... : only this node's ranks share its cores
+    assert dist.host_threads_per_rank(10_000, C()) == max(1, cpus // 2)
+    assert dist.host_threads_per_rank(1) == 1 and dist.host_threads_per_rank(None) == 1
+    # and that is what the sharded file jobs hand to the native pipelines
+    seen = {}
+    from blaze_amd import putative_bc, read_assignment as ra
+    monkeypatch.setattr(putative_bc, "putative_bc_files", lambda engines, fns, out, **kw: seen.update(kw) or {})
+    monkeypatch.setattr(ra, "get_engine", lambda d: None)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    f = os.path.join(ROOT, "bench.py")
+    dist.putative_bc_files_sharded(dist.LocalComm(), [f], "/tmp/never_written.csv", "3v3", 12, 15, 1000, 16, device=0)
+    assert seen["n_threads"] == max(1, min(16, cpus) // 4)
+    monkeypatch.setattr(ra, "_ensure_whitelist", lambda e, o: None)
+    monkeypatch.setattr(ra, "_assign_files_native", lambda engines, fns, csv, out, gz, restrand, max_ed, bs, dbr, threads, **kw: (threads, 0))
+    wl = os.path.join(ROOT, "BASELINE.md")
+    run = dist.native_run_rank("x.csv", wl, 2, 16, 1000, device=0, comm=None)
+    assert run([f], "/tmp/never_written.fastq", 0)[0] == max(1, min(16, cpus) // 4)
+
+
+def test_rank0_failure_in_stage_2_releases_the_other_ranks(tmp_path):
+    """Rank 0 alone runs stage 2; when it raises there (the reference's own FileNotFoundError on a job without reads) the
+    other ranks must leave the collective they wait in, not hang."""
+    import threading
+    import types
+    from blaze_amd import main as bmain
+    shared = {"bar": threading.Barrier(2, timeout=60), "lock": threading.Lock()}
+    args = types.SimpleNamespace(do_bc_search=False, do_whitelisting=True, do_demultiplexing=True, minQ=15,
+                                 out_raw_bc_fn=str(tmp_path / "no_such_table.csv"), fastq_fns=[])
+    res = {}
+
+    def rank_main(r):
+        try:
+            bmain.main(args, devices=[0], comm=_ThreadComm(r, 2, shared))
+            res[r] = "returned"
+        except BaseException as e:      # noqa: BLE001
+            res[r] = type(e).__name__
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(90)
+    assert not any(t.is_alive() for t in ts)
+    assert res[0] == "FileNotFoundError" and res[1] == "SystemExit", res

@@ -347,6 +347,171 @@ def locate_first_row(putative_bc_csv, fastq_fns, lo, hi):
     return None if off.value < 0 else int(off.value)
 
 
+def partition_groups(sizes, world: int, per_rank: int = 4, min_bytes: int | None = None):
+    """Contiguous runs of the job's FASTQ files that are dealt to the ranks ROUND ROBIN (group g -> rank g % world):
+    up to `per_rank` groups per rank, none smaller than `min_bytes` unless that leaves a rank without one, balanced by
+    bytes.  Small groups are what lets a rank put a finished group into the output while the next one is computed
+    (Ledger): the offset of a group only needs the groups in front of it, which the other ranks finish at about the same time."""
+    n = len(sizes)
+    if n == 0:
+        return []
+    if min_bytes is None:
+        min_bytes = int(os.environ.get("BLAZE_AMD_GROUP_MIN_BYTES", str(64 << 20)))
+    total = sum(sizes)
+    want = max(world, min(world * per_rank, int(total // max(1, min_bytes))))
+    return [(lo, hi) for lo, hi in partition_files(sizes, min(n, want)) if hi > lo]
+
+
+class Ledger:
+    """Where the groups of a file-sharded job go in the ONE output file: a small file beside it, mapped by every rank of the
+    node, end[g] = offset behind group g (-1 = not known yet).  The rank that finishes group g waits until end[g - 1] is
+    known, publishes end[g] = end[g - 1] + its size, and then writes its bytes at end[g - 1] -- the wait is short (the groups
+    in front are being finished by the other ranks at the same time) and the bytes of the output are written ONCE, by all
+    ranks side by side, while later groups are still being computed.  Single node (a shared file mapping); a rank that fails
+    sets the abort flag so that nobody waits for its groups."""
+
+    def __init__(self, path, n_groups, comm):
+        import mmap
+        self.path, self.n, self.comm = path, n_groups, comm
+        size = 8 * (n_groups + 2)
+        if comm.rank == 0:
+            with open(path, "wb") as f:
+                f.write(np.concatenate([[0], np.full(n_groups, -1), [0]]).astype(np.int64).tobytes())
+        comm.barrier()
+        self._f = open(path, "r+b")
+        self._m = mmap.mmap(self._f.fileno(), size)
+        self.v = np.frombuffer(self._m, dtype=np.int64)          # v[0] = 0, v[g + 1] = end of group g, v[-1] = abort flag
+
+    def reserve(self, g, size_at, timeout_s=None):
+        """Offset of group g once every group in front of it has reserved; publishes this group's end = offset +
+        size_at(offset) (the size may depend on the offset: only the first bytes of a table keep their header line)."""
+        deadline = time.time() + float(timeout_s if timeout_s is not None else os.environ.get("BLAZE_AMD_HUB_TIMEOUT", "1800"))
+        pause = 0.0002
+        while self.v[g] < 0:
+            if self.v[-1]:
+                raise RuntimeError("another rank of the sharded job failed; its groups will never be placed")
+            if time.time() > deadline:
+                raise TimeoutError(f"group {g}: the groups in front of it were not placed in time")
+            time.sleep(pause)
+            pause = min(pause * 2, 0.005)
+        off = int(self.v[g])
+        size = int(size_at(off))
+        self.v[g + 1] = off + size
+        return off, size
+
+    def abort(self):
+        self.v[-1] = 1
+
+    def close(self, remove=False):
+        self.v = None
+        try:
+            self._m.close()
+        except BufferError:
+            pass
+        self._f.close()
+        if remove and os.path.exists(self.path):
+            os.remove(self.path)
+
+
+def _place_file(src_path, dst_fd, dst_off, skip=0):
+    """All bytes of src_path behind its first `skip` to dst_fd at dst_off, through a large user buffer (pread / pwrite of
+    8 MiB pieces moved 12-15 GB/s into one file from 2-8 processes on the box's ext4, copy_file_range 5-7 GB/s:
+    profiles/r03b_place_parts.txt), then the part is removed."""
+    src = os.open(src_path, os.O_RDONLY)
+    try:
+        off = skip
+        while True:
+            buf = os.pread(src, 8 << 20, off)
+            if not buf:
+                break
+            done = 0
+            while done < len(buf):
+                done += os.pwrite(dst_fd, buf[done:] if done else buf, dst_off + (off - skip) + done)
+            off += len(buf)
+    finally:
+        os.close(src)
+    os.remove(src_path)
+
+
+def run_groups(comm, out_path, groups, run_group, n_sums, drop_header=False, create_empty=True):
+    """Group g of files -> rank g % world -> `run_group(g, lo, hi, part)` writes the group's part and returns n_sums
+    counts -> the part goes into `out_path` at the offset the Ledger gives it, placed by a helper thread while the rank
+    computes its next group.  drop_header: every part starts with the same header line and only the bytes at offset 0 keep
+    it (the stage-1 table).  create_empty: the output exists even when no group wrote a byte (step 3: the reference opens
+    it before the first batch, read_assignment.py:296,322; the stage-1 table is only made with the first batch,
+    main.py:361).  Returns the counts summed over all groups and ranks."""
+    import queue
+    import threading
+    if comm.rank == 0:
+        import glob
+        gz = str(out_path).endswith('.gz')
+        stem = str(out_path)[:-3] if gz else str(out_path)
+        for stale in glob.glob(glob.escape(stem) + ".part[0-9][0-9][0-9][0-9]*" + ('.gz' if gz else '')):
+            os.remove(stale)                         # parts of an earlier run that died: not this run's bytes
+        if os.path.exists(out_path):
+            os.remove(out_path)                      # an earlier run's: the placers below create, they never truncate
+        if create_empty:
+            open(out_path, "wb").close()
+    ledger = Ledger(str(out_path) + ".ledger", len(groups), comm)      # (its barrier is also the one behind the lines above)
+    todo, errs = queue.Queue(), []
+
+    def placer():
+        fd = -1
+        try:
+            while True:
+                item = todo.get()
+                if item is None:
+                    return
+                g, part = item
+                if errs:
+                    continue
+                try:
+                    size = os.path.getsize(part) if os.path.exists(part) else 0
+                    head = 0
+                    if drop_header and size:
+                        with open(part, "rb") as f:
+                            head = len(f.readline())
+                    off, eff = ledger.reserve(g, lambda o: size - (head if o > 0 else 0))
+                    if eff > 0:
+                        if fd < 0:
+                            fd = os.open(out_path, os.O_WRONLY | os.O_CREAT, 0o666)
+                        _place_file(part, fd, off, skip=size - eff)
+                    elif os.path.exists(part):
+                        os.remove(part)
+                except BaseException as e:      # noqa: BLE001  (raised by the rank's main thread below)
+                    errs.append(e)
+                    ledger.abort()
+        finally:
+            if fd >= 0:
+                os.close(fd)
+    th = threading.Thread(target=placer, daemon=True)
+    th.start()
+    sums = np.zeros(n_sums, dtype=np.int64)
+    try:
+        for g in range(comm.rank, len(groups), comm.world):
+            if errs:
+                break
+            part = part_path(out_path, g)
+            if os.path.exists(part):
+                os.remove(part)                      # a dead run's: a group without reads may write no part at all
+            sums += np.asarray(run_group(g, groups[g][0], groups[g][1], part), dtype=np.int64)
+            todo.put((g, part))
+    except BaseException:
+        ledger.abort()
+        todo.put(None)
+        th.join()
+        ledger.close()
+        raise
+    todo.put(None)
+    th.join()
+    if errs:
+        ledger.close()
+        raise errs[0]
+    sums = comm.allreduce_sum_i64(sums)              # also the barrier behind every rank's writes
+    ledger.close(remove=comm.rank == 0)
+    return sums
+
+
 def native_run_rank(putative_bc_csv, whitelsit_csv, max_ed, n_process, batchsize, restrand=True, device=None, comm=None):
     """What one rank does with its files in assign_read_sharded: the native device pipeline (bz_assign_files_from) on this
     process's GPU, `csv_skip_rows` rows of the table skipped, on this rank's share of the host threads
@@ -373,15 +538,20 @@ def native_run_rank(putative_bc_csv, whitelsit_csv, max_ed, n_process, batchsize
 def assign_read_sharded(comm, fastq_fns, fastq_out, putative_bc_csv, whitelsit_csv, max_ed, n_process, batchsize,
                         restrand=True, device=None, count_reads=count_fastq_reads, run_rank=None):
     """assign_read (read_assignment.py:253-330) with the FASTQ files sharded over the ranks of `comm`, one process
-    per GPU: rank r takes a contiguous run of files (balanced by bytes), counts the reads of its own files, learns
-    from the other ranks' counts how many rows of putative_bc.csv precede its files, demultiplexes its files into
-    `part_path(fastq_out, r)`, and after ONE all-reduce of the part sizes every rank places its own bytes at its own
-    offset of `fastq_out`, all ranks at once (place_parts; gzip members concatenate; plain text concatenates: the
-    bytes are those of a single-process run).  The scan
-    uses no collective; the two totals are summed once.  Returns the GLOBAL (reads assigned, reads seen)."""
+    per GPU.  First choice (plain table): the files are cut into groups dealt round robin (partition_groups), a rank finds
+    where a group's rows of putative_bc.csv start from the id of the group's first read (locate_first_row),
+    demultiplexes the group into a part, and a helper thread puts the part into `fastq_out` at the offset the Ledger
+    gives it while the rank computes its next group: the output's bytes are written once, by all ranks side by side
+    (run_groups).  Otherwise (gzipped table, quoted ids): rank r takes ONE contiguous run of files, counts the reads of its
+    own files, learns from the other ranks' counts how many rows precede them, writes `part_path(fastq_out, r)`, and after
+    one all-reduce of the part sizes every rank copies its part to its offset (place_parts).  Either way gzip members and
+    plain text concatenate to the bytes of a single-process run (reference batches never span files,
+    read_assignment.py:149-158), the scan uses no collective and the two totals are summed once.
+    Returns the GLOBAL (reads assigned, reads seen)."""
     from . import read_assignment as ra
     fastq_fns = [str(f) for f in fastq_fns]
-    spans = partition_files([os.path.getsize(f) for f in fastq_fns], comm.world)
+    sizes = [os.path.getsize(f) for f in fastq_fns]
+    spans = partition_files(sizes, comm.world)
     lo, hi = spans[comm.rank]
     part = part_path(fastq_out, comm.rank)
     if hi <= lo and os.path.exists(part):
@@ -391,16 +561,20 @@ def assign_read_sharded(comm, fastq_fns, fastq_out, putative_bc_csv, whitelsit_c
     # Where do this rank's rows of the table start?  First choice: find the row of its first read in the table itself (no
     # FASTQ byte is read twice); every rank must succeed, else all fall back to counting the reads of their own files and
     # one all-reduce of the counts.
-    offset = None
+    if comm.world == 1 and count_reads is count_fastq_reads:
+        return tuple(int(x) for x in run_rank(fastq_fns, fastq_out, 0))       # nothing to shard: straight into the output
     if getattr(run_rank, "takes_byte_offset", False) and count_reads is count_fastq_reads and os.environ.get("BLAZE_AMD_CSV_LOCATE", "1") != "0":
-        offset = locate_first_row(putative_bc_csv, fastq_fns, lo, hi) if hi > lo else 0
-        found = comm.allreduce_sum_i64(np.array([0 if offset is None else 1], dtype=np.int64))
-        if int(found[0]) != comm.world:
-            offset = None
-    if offset is not None:
-        demul, total = run_rank(fastq_fns[lo:hi], part, None, csv_byte_offset=offset) if hi > lo else (0, 0)
-        sums = place_parts(comm, fastq_out, part, extra_sums=(demul, total))
-        return int(sums[0]), int(sums[1])
+        groups = partition_groups(sizes, comm.world)
+        offsets, ok = {}, 1
+        for g in range(comm.rank, len(groups), comm.world):
+            offsets[g] = locate_first_row(putative_bc_csv, fastq_fns, groups[g][0], groups[g][1])
+            if offsets[g] is None:
+                ok = 0
+                break
+        found = comm.allreduce_sum_i64(np.array([ok], dtype=np.int64))
+        if int(found[0]) == comm.world:
+            sums = run_groups(comm, fastq_out, groups, lambda g, lo, hi, part: run_rank(fastq_fns[lo:hi], part, None, csv_byte_offset=offsets[g]), 2)
+            return int(sums[0]), int(sums[1])
     mine = np.zeros(comm.world, dtype=np.int64)
     # counting gzipped files means inflating them: the files of this rank side by side (the native counter drops the GIL)
     from concurrent.futures import ThreadPoolExecutor
@@ -476,7 +650,9 @@ def make_comm(engine=None, try_rccl=True, init_timeout_s=None):
 def _copy_range(src_fd, dst_fd, count, src_off, dst_off):
     """count bytes from src_fd@src_off to dst_fd@dst_off inside the kernel (copy_file_range: no pass through user
     space, reflink where the file system has it); pread / pwrite where the call is not available."""
-    use_cfr = hasattr(os, "copy_file_range")
+    # copy_file_range pays off where the file system shares extents (XFS / btrfs reflinks: no byte moves); on ext4 it moved
+    # 5-7 GB/s into one file against 12-15 GB/s for large pread / pwrite pieces (profiles/r03b_place_parts.txt): opt in
+    use_cfr = hasattr(os, "copy_file_range") and os.environ.get("BLAZE_AMD_COPY_FILE_RANGE", "0") == "1"
     while count > 0:
         if use_cfr:
             try:
@@ -485,7 +661,7 @@ def _copy_range(src_fd, dst_fd, count, src_off, dst_off):
                 use_cfr = False
                 continue
         else:
-            buf = os.pread(src_fd, min(count, 1 << 24), src_off)
+            buf = os.pread(src_fd, min(count, 8 << 20), src_off)
             n = len(buf)
             done = 0
             while done < n:
@@ -549,17 +725,17 @@ def putative_bc_files_sharded(comm, fastq_fns, out_csv, kit, umi_len, min_q, bat
     share (host_threads_per_rank).  Returns the GLOBAL {pass code: reads}."""
     from . import putative_bc, read_assignment as ra
     fastq_fns = [str(f) for f in fastq_fns]
-    lo, hi = partition_files([os.path.getsize(f) for f in fastq_fns], comm.world)[comm.rank]
-    part = part_path(out_csv, comm.rank)
-    if os.path.exists(part):
-        os.remove(part)                              # an earlier run's: the stage-1 writer creates the table only when it has reads
     if run_rank is None:
         def run_rank(fns, out):
             eng = ra.get_engine(device if device is not None else ra._device_ids(None)[0])
             return putative_bc.putative_bc_files([eng], fns, out, kit=kit, umi_len=umi_len, min_q=min_q, batch_size=batch_size,
                                                  n_threads=host_threads_per_rank(n_threads, comm))
-    counts = run_rank(fastq_fns[lo:hi], part) if hi > lo else {}
     codes = (0, 1, 2, 10, 100)
+    groups = partition_groups([os.path.getsize(f) for f in fastq_fns], comm.world)
+
+    def run_group(g, lo, hi, part):
+        counts = run_rank(fastq_fns[lo:hi], part)
+        return [counts.get(c, 0) for c in codes]
     # no reads at all: the reference never creates the table (main.py:361)
-    sums = place_parts(comm, out_csv, part, extra_sums=[counts.get(c, 0) for c in codes], drop_header=True, create_empty=False)
+    sums = run_groups(comm, out_csv, groups, run_group, len(codes), drop_header=True, create_empty=False)
     return {c: int(v) for c, v in zip(codes, sums) if v}

@@ -508,3 +508,97 @@ def test_rank0_failure_in_stage_2_releases_the_other_ranks(tmp_path):
         t.join(90)
     assert not any(t.is_alive() for t in ts)
     assert res[0] == "FileNotFoundError" and res[1] == "SystemExit", res
+
+
+def _grouped_job(tmp_path, reads):
+    """FASTQ files with `reads[k]` reads each and their table; -> (fns, csv path, byte offset of every file's first row)."""
+    fns, rows, starts = [], ["read_id,putative_bc,putative_bc_min_q,putative_umi,polyT_end,pre_bc_flanking,post_umi_flanking\n"], []
+    for f, n in enumerate(reads):
+        fn = tmp_path / f"g{f}.fastq"
+        fn.write_text("".join(f"@read-{f}-{i} runid=x\nACGT\n+\nIIII\n" for i in range(n)))
+        fns.append(str(fn))
+        starts.append(len("".join(rows)))
+        rows += [f"read-{f}-{i},ACGTACGTACGTACGT,15,ACGTACGTACGT,300,ACGTA,TTTTT\n" for i in range(n)]
+    csv = tmp_path / "putative_bc.csv"
+    csv.write_text("".join(rows))
+    return fns, str(csv), starts
+
+
+def _ranks_as_threads(world, body):
+    import threading
+    shared = {"bar": threading.Barrier(world, timeout=60), "lock": threading.Lock()}
+    res, errs = {}, {}
+
+    def rank_main(r):
+        try:
+            res[r] = body(_ThreadComm(r, world, shared))
+        except BaseException as e:      # noqa: BLE001
+            errs[r] = e
+            shared["bar"].abort()
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not any(t.is_alive() for t in ts)
+    return res, errs
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_groups_round_robin_are_placed_in_file_order(tmp_path, monkeypatch, world):
+    """The located-row route: groups of files dealt round robin, every group's part placed at the offset the ledger gives
+    it by a helper thread -- the output is the files' outputs in file order, whatever order the groups finish in."""
+    import time
+    from blaze_amd import dist
+    monkeypatch.setenv("BLAZE_AMD_GROUP_MIN_BYTES", "1")            # tiny files: still several groups per rank
+    reads = [5, 0, 700, 30, 0, 0, 1500, 1, 260, 40, 900, 3, 77]
+    fns, csv, starts = _grouped_job(tmp_path, reads)
+    out = str(tmp_path / "out.fastq")
+    seen = []
+
+    def body(comm):
+        def run_rank(files, part, skip, csv_byte_offset=None):
+            first = next((f for f in files if os.path.getsize(f)), None)
+            assert skip is None and csv_byte_offset == (starts[fns.index(first)] if first else 0)
+            time.sleep(0.002 * ((len(files) * 7 + comm.rank) % 5))     # groups finish out of order
+            n = 0
+            with open(part, "wb") as o:
+                for f in files:
+                    for line in open(f, "rb"):
+                        if line.startswith(b"@"):
+                            o.write(line)
+                            n += 1
+            seen.append((comm.rank, [os.path.basename(f) for f in files]))
+            return n // 2, n
+        run_rank.takes_byte_offset = True
+        return dist.assign_read_sharded(comm, fns, out, csv, "unused", 2, 4, 1000, run_rank=run_rank)
+    res, errs = _ranks_as_threads(world, body)
+    assert not errs, errs
+    expect = b"".join(f"@read-{f}-{i} runid=x\n".encode() for f, n in enumerate(reads) for i in range(n))
+    assert open(out, "rb").read() == expect
+    total = sum(reads)
+    assert all(res[r] == res[0] and res[r][1] == total for r in range(world))
+    groups = dist.partition_groups([os.path.getsize(f) for f in fns], world)
+    assert world < len(groups) <= 4 * world                                                         # several groups per rank
+    assert sorted(x for _, fl in seen for x in fl) == sorted(os.path.basename(f) for f in fns)      # every file once
+    assert {r for r, _ in seen} == set(range(min(world, len(groups))))                              # dealt over the ranks
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f or f.endswith(".ledger")]
+
+
+def test_a_failing_rank_releases_the_ranks_that_wait_for_its_groups(tmp_path, monkeypatch):
+    from blaze_amd import dist
+    monkeypatch.setenv("BLAZE_AMD_GROUP_MIN_BYTES", "1")
+    fns, csv, _ = _grouped_job(tmp_path, [50, 60, 70, 80, 90, 100])
+    out = str(tmp_path / "out.fastq")
+
+    def body(comm):
+        def run_rank(files, part, skip, csv_byte_offset=None):
+            if comm.rank == 0:
+                raise ValueError("rank 0 cannot read its file")
+            with open(part, "wb") as o:
+                o.write(b"x" * 10)
+            return 1, 1
+        run_rank.takes_byte_offset = True
+        return dist.assign_read_sharded(comm, fns, out, csv, "unused", 2, 4, 1000, run_rank=run_rank)
+    res, errs = _ranks_as_threads(2, body)
+    assert isinstance(errs[0], ValueError) and 1 in errs and not res, (res, errs)

@@ -21,7 +21,8 @@ sys.path.insert(0, ROOT)
 def worker(d, gz, threads):
     from blaze_amd import dist
     comm = dist.make_comm(init_timeout_s=60)
-    fns = sorted(os.path.join(d, f) for f in os.listdir(d) if f.startswith("reads_") and f.endswith(".fastq"))
+    fns = sorted((os.path.join(d, f) for f in os.listdir(d) if f.startswith("reads_") and f.endswith(".fastq")),
+                 key=lambda f: int(os.path.basename(f)[6:-6]))         # the order the table was written in
     out = os.path.join(d, f"sharded_w{comm.world}.fastq" + (".gz" if gz else ""))
     best = None
     for rep in range(3):
@@ -36,7 +37,7 @@ def worker(d, gz, threads):
         import gzip
         raw = open(out, "rb").read()
         text = gzip.decompress(raw) if gz else raw
-        print(json.dumps({"world": comm.world, "threads_per_rank": threads, "comm": comm.kind, "why": getattr(comm, "why", ""), "s": best,
+        print(json.dumps({"world": comm.world, "threads_per_rank": dist.host_threads_per_rank(threads, comm), "comm": comm.kind, "why": getattr(comm, "why", ""), "s": best,
                           "assigned": int(got[0]), "total": int(got[1]), "sha1_of_text": hashlib.sha1(text).hexdigest(), "bytes_out": len(raw)}), flush=True)
     comm.barrier()
     if getattr(comm, "hung", False):
@@ -54,18 +55,19 @@ def main():
     gz = "--gz" in sys.argv
     from blaze_amd import synth
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
-        synth.write_file_job(d, n, n_cells, n_files=8)
+        synth.write_file_job(d, n, n_cells, n_files=int(os.environ.get('N_FILES', '32')))
         out = {"reads": n, "cells": n_cells, "gz": gz, "runs": []}
-        for world in (1, 2, 4):
+        for world in [int(w) for w in os.environ.get('WORLDS', '1,2,4,8').split(',')]:
             with socket.socket() as s:
                 s.bind(("127.0.0.1", 0))
                 port = s.getsockname()[1]
             procs = []
             for rank in range(world):
-                env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                            PYTHONHASHSEED="0")       # the same set() order of the whitelist in every process: comparable bytes
                 procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", d, "1" if gz else "0",
-                                               str(max(1, total_threads // world))], env=env, stdout=subprocess.PIPE, text=True))
+                                               str(total_threads)], env=env     # the HOST's budget: the library gives every rank its share
+                                              , stdout=subprocess.PIPE, text=True))
             lines = [p.communicate(timeout=600)[0] for p in procs]
             if any(p.returncode for p in procs):
                 raise SystemExit(f"world {world}: rank exit codes {[p.returncode for p in procs]}")

@@ -28,6 +28,21 @@ EXPORTS = [
 ]
 
 
+def source_sha256() -> str:
+    """Hash of the sources libblaze_hip.so is built from (blaze_amd/csrc/*, include/blaze_hip.h): what a committed
+    rocprof counter file is tied to -- bench.py joins its instruction counts with live timings only while this matches."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*"))) + [os.path.join(os.path.dirname(_HERE), "include", "blaze_hip.h")]
+    for fn in files:
+        if os.path.isfile(fn):
+            h.update(os.path.basename(fn).encode() + b"\0")
+            with open(fn, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
 class BlazeHipError(RuntimeError):
     """A negative status from the C ABI (map to RuntimeError)."""
 

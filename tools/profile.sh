@@ -17,5 +17,8 @@ pass trace --kernel-trace --stats
 pass pmc_sq --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_INSTS_LDS
 pass pmc_fetch --pmc FETCH_SIZE GRBM_GUI_ACTIVE
 pass pmc_write --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+# lanes: thread-cycles of VALU work over wave-level VALU cycles x 64 = the share of the issued lane slots that held an
+# ACTIVE lane (rocprofv3's derived VALUUtilization is this ratio); SQ_INSTS_VALU alone counts masked-off lanes as work
+pass pmc_lanes --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
 python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.md"
 cat "$OUT/summary.md"

@@ -51,14 +51,22 @@ for k in durs:
 # counters: kernel -> [dispatch -> {counter: value}] in dispatch order
 pmc = defaultdict(lambda: defaultdict(dict))
 meta = {}
-for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
+for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_lanes"):
     for r in rows(f"{sub}/**/*counter_collection.csv"):
         k = short(r.get("Kernel_Name", ""))
         pmc[k][(sub, int(r.get("Dispatch_Id")))][r.get("Counter_Name")] = float(r.get("Counter_Value", 0))
         meta[k] = dict(vgpr=r.get("VGPR_Count"), sgpr=r.get("SGPR_Count"), lds=r.get("LDS_Block_Size"),
                        grid=r.get("Grid_Size"), workgroup=r.get("Workgroup_Size"))
 
-result = {"source": out, "kernels": {}}
+import hashlib
+LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "blaze_amd", "lib", "libblaze_hip.so")
+with open(LIB, "rb") as f:
+    lib_sha = hashlib.sha256(f.read()).hexdigest()
+# the library these counters were taken on: bench.py joins them with LIVE timings only while the hash still matches
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from blaze_amd import _lib as _bz_lib  # noqa: E402
+src_sha = _bz_lib.source_sha256()
+result = {"source": out, "library_sha256": lib_sha, "source_sha256": src_sha, "kernels": {}}
 try:                                                 # the workload the passes ran (bench.py's own line of the trace pass)
     with open(os.path.join(out, "trace.json")) as f:
         line = [ln for ln in f if ln.startswith("{")][-1]
@@ -96,7 +104,10 @@ for k in sorted(pmc):
             for n in names:
                 vals = [lst[i].get(n) for i in idx if lst[i].get(n) is not None]
                 if vals:
-                    c[n] = sum(vals) / len(vals)
+                    c[n if sub != "pmc_lanes" else "LANES_" + n] = sum(vals) / len(vals)
+        if c.get("LANES_SQ_ACTIVE_INST_VALU"):
+            # = rocprofv3's VALUUtilization / 100: active lanes per issued VALU lane slot
+            c["lane_utilisation"] = c["LANES_SQ_THREAD_CYCLES_VALU"] / (c["LANES_SQ_ACTIVE_INST_VALU"] * 64.0)
         entry["classes"][cname] = c
         print(f"**{cname}** ({len(idx)} dispatches" + (f", avg {c['avg_us']:.1f} us" if "avg_us" in c else "") + ")\n")
         print("| counter | mean per dispatch |")
@@ -109,6 +120,8 @@ for k in sorted(pmc):
 
 with open(os.path.join(out, "pmc.json"), "w") as f:
     json.dump(result, f, indent=1, sort_keys=True)
+print(f"Library profiled: sources sha256 {src_sha} (blaze_amd/csrc + include/blaze_hip.h), binary sha256 {lib_sha}.  lane_utilisation = SQ_THREAD_CYCLES_VALU / "
+      "(SQ_ACTIVE_INST_VALU x 64) of the pmc_lanes pass (rocprofv3's VALUUtilization): the share of issued VALU lane slots with an active lane.\n")
 print("Units: FETCH_SIZE / WRITE_SIZE are KiB as rocprofv3 reports them (gfx950: FETCH_SIZE counts a wide "
       "coalesced read at half its bytes, MI355X_MICROARCH.md 'HBM'); SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are "
       "quad-cycles summed over waves; SQ_INSTS_* are wave-instructions; GRBM_GUI_ACTIVE sums the 8 XCDs.")

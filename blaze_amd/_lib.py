@@ -52,6 +52,33 @@ class BlazeFileNotFoundError(BlazeHipError, FileNotFoundError):
     reference's own `open()` calls raise for the same paths (read_assignment.py:149-153, :279; main.py:311-315)."""
 
 
+class BlazePermissionError(BlazeHipError, PermissionError):
+    """EACCES / EPERM from the native open(): the PermissionError the reference's `open()` raises."""
+
+
+class BlazeIsADirectoryError(BlazeHipError, IsADirectoryError):
+    """A directory where a file was expected: the IsADirectoryError the reference's `open()` raises."""
+
+
+class BlazeOSError(BlazeHipError, OSError):
+    """Any other errno of a native open() / mmap()."""
+
+
+def _os_error(rc: int, text: str):
+    """The native open / map failures carry '[errno N: ...]' (host_io.h: open_error): raise what Python's own open() would."""
+    import errno as _errno
+    import re
+    m = re.search(r"\[errno (\d+): ", text)
+    if not m:
+        return None
+    code = int(m.group(1))
+    cls = {_errno.ENOENT: BlazeFileNotFoundError, _errno.ENOTDIR: BlazeFileNotFoundError, _errno.EACCES: BlazePermissionError,
+           _errno.EPERM: BlazePermissionError, _errno.EISDIR: BlazeIsADirectoryError}.get(code, BlazeOSError)
+    e = cls(f"libblaze_hip status {rc}: {text}")
+    e.errno, e.strerror = code, f"libblaze_hip status {rc}: {text}"          # (RuntimeError comes first in the MRO: OSError's own constructor does not fill these)
+    return e
+
+
 _lib = None
 
 
@@ -127,7 +154,8 @@ def check(rc: int) -> int:
     if rc < 0:
         msg = load().bz_last_error()
         text = msg.decode(errors='replace') if msg else ''
-        if text.startswith(("cannot open ", "cannot map ")):
-            raise BlazeFileNotFoundError(f"libblaze_hip status {rc}: {text}")
+        err = _os_error(rc, text)
+        if err is not None:
+            raise err
         raise BlazeHipError(f"libblaze_hip status {rc}: {text}")
     return rc

@@ -21,6 +21,8 @@
 #include <immintrin.h>
 #endif
 #include <dlfcn.h>
+#include <errno.h>
+#include <string.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -50,6 +52,12 @@ struct Span { char *p = nullptr; uint32_t len = 0; };          // bytes live in 
 inline bool py_space(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x1f); }
 
 // ---- stable storage for lines that have to be copied (gzip input): blocks never move ----------------------------
+// "cannot open <path>[ for writing] [errno N: text]": the Python layer raises the OSError subclass of N (the reference's own
+// open() calls raise FileNotFoundError / IsADirectoryError / PermissionError for the same paths)
+inline std::runtime_error open_error(const std::string &what, int err) {
+    return std::runtime_error(what + " [errno " + std::to_string(err) + ": " + strerror(err) + "]");
+}
+
 class Arena {
    public:
     char *alloc(size_t n) {
@@ -92,13 +100,14 @@ class MmapLines : public LineSource {
    public:
     explicit MmapLines(const std::string &path, size_t start = 0) {
         fd_ = open(path.c_str(), O_RDONLY);
-        if (fd_ < 0) throw std::runtime_error("cannot open " + path);
+        if (fd_ < 0) throw open_error("cannot open " + path, errno);
         struct stat st;
-        if (fstat(fd_, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd_); fd_ = -1; throw std::runtime_error("cannot map " + path); }
+        if (fstat(fd_, &st) != 0) { const int e = errno; close(fd_); fd_ = -1; throw open_error("cannot map " + path, e); }
+        if (!S_ISREG(st.st_mode)) { close(fd_); fd_ = -1; throw open_error("cannot map " + path, S_ISDIR(st.st_mode) ? EISDIR : EINVAL); }
         size_ = (size_t)st.st_size;
         if (size_) {
             void *m = mmap(nullptr, size_, PROT_READ | PROT_WRITE, MAP_PRIVATE, fd_, 0);
-            if (m == MAP_FAILED) { close(fd_); fd_ = -1; throw std::runtime_error("cannot map " + path); }
+            if (m == MAP_FAILED) { const int e = errno; close(fd_); fd_ = -1; throw open_error("cannot map " + path, e); }
             base_ = (char *)m;
             start_ = std::min(start, size_);                      // a rank of a sharded run starts at ITS first row of the table
             at_.store(start_, std::memory_order_relaxed);
@@ -158,7 +167,7 @@ class GzLines : public LineSource {
    public:
     explicit GzLines(const std::string &path) : path_(path) {
         f_ = gzopen(path.c_str(), "rb");
-        if (!f_) throw std::runtime_error("cannot open " + path);
+        if (!f_) throw open_error("cannot open " + path, errno ? errno : ENOENT);
         gzbuffer(f_, 1 << 20);
         buf_.resize(8 << 20);
     }
@@ -232,6 +241,7 @@ inline bool ends_with_gz(const std::string &p) { return p.size() >= 3 && p.compa
 inline std::shared_ptr<LineSource> open_lines(const std::string &path) {      // '.gz' decides, as read_assignment.py:151
     if (ends_with_gz(path)) return std::make_shared<GzLines>(path);
     struct stat st;
+    if (stat(path.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) throw open_error("cannot open " + path, EISDIR);   // Python's open(): IsADirectoryError
     if (stat(path.c_str(), &st) == 0 && !S_ISREG(st.st_mode)) return std::make_shared<GzLines>(path);   // pipes etc.: streamed
     return std::make_shared<MmapLines>(path);
 }
@@ -255,6 +265,10 @@ class FastqFiles {
             struct stat st;
             slots_[k].prefetch = enabled && ends_with_gz(paths_[k]) && stat(paths_[k].c_str(), &st) == 0 && S_ISREG(st.st_mode) &&
                                  (int64_t)st.st_size <= kStreamAbove;
+            // what the file will hold once inflated, as far as its size tells (FASTQ deflates ~4x): reserved against the budget
+            // from the moment a worker takes the file, corrected when it is done -- a budget that only saw finished files let
+            // every worker start a 512 MiB file at once and hold tens of GB before the first one was counted
+            if (slots_[k].prefetch) slots_[k].est = (int64_t)st.st_size * 4;
             n_prefetch_ += slots_[k].prefetch;
         }
         if (const char *b = getenv("BLAZE_AMD_GZ_PREFETCH_MB")) budget_ = std::max<int64_t>(1, atoll(b)) << 20;
@@ -292,7 +306,7 @@ class FastqFiles {
     }
 
    private:
-    struct Slot { bool prefetch = false, started = false, done = false; std::unique_ptr<char[]> buf; size_t size = 0; std::exception_ptr err; };
+    struct Slot { bool prefetch = false, started = false, done = false; std::unique_ptr<char[]> buf; size_t size = 0; int64_t est = 0; std::exception_ptr err; };
     struct Shared { std::mutex mu; std::condition_variable cv; int64_t bytes = 0; };     // outlives this object: chunks free buffers later
     void work() {
         for (;;) {
@@ -305,13 +319,15 @@ class FastqFiles {
                     while (k < slots_.size() && (!slots_[k].prefetch || slots_[k].started)) ++k;
                     if (k >= slots_.size()) return;
                     // the file the reader is waiting for is always taken; others only inside the window and the budget
+                    // (bytes = inflated text held + the estimates of the files being inflated right now)
                     bool room;
-                    { std::lock_guard<std::mutex> g(state_->mu); room = state_->bytes < budget_; }
+                    { std::lock_guard<std::mutex> g(state_->mu); room = state_->bytes + slots_[k].est <= budget_ || state_->bytes == 0; }
                     if (k <= next_needed_ || (k < next_needed_ + ahead_ && room)) break;
                     cv_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(20));   // (system clock: pthread_cond_timedwait, which ThreadSanitizer understands)
                 }
                 slots_[k].started = true;
                 scan_ = k + 1;
+                { std::lock_guard<std::mutex> g(state_->mu); state_->bytes += slots_[k].est; }
             }
             std::unique_ptr<char[]> buf;
             size_t size = 0;
@@ -323,7 +339,7 @@ class FastqFiles {
             }
             {
                 std::lock_guard<std::mutex> g(mu_);
-                { std::lock_guard<std::mutex> g2(state_->mu); state_->bytes += (int64_t)size; }
+                { std::lock_guard<std::mutex> g2(state_->mu); state_->bytes += (int64_t)size - slots_[k].est; }   // the estimate becomes the real size
                 slots_[k].buf = std::move(buf);
                 slots_[k].size = size;
                 slots_[k].err = err;
@@ -397,7 +413,7 @@ class FastqFiles {
         size_t whole = 0;
         if (inflate_whole(path, out, whole)) return whole;
         gzFile f = gzopen(path.c_str(), "rb");                  // multi-member files and plain text behind a .gz name included
-        if (!f) throw std::runtime_error("cannot open " + path);
+        if (!f) throw open_error("cannot open " + path, errno ? errno : ENOENT);
         gzbuffer(f, 1 << 20);
         struct stat st;
         size_t cap = (size_t)4 << 20;
@@ -733,7 +749,7 @@ struct OrderedPipeline {
         auto open_out = [&]() {
             if (fo) return;
             fo = fopen(out_path.c_str(), "wb");
-            if (!fo) throw std::runtime_error("cannot open " + out_path + " for writing");
+            if (!fo) throw open_error("cannot open " + out_path + " for writing", errno);
         };
         auto finish_oldest = [&]() {
             auto old = std::move(inflight.front());

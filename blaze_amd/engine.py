@@ -52,11 +52,31 @@ class PinnedRows:
         self.ext[...], self.ext_len[...], self.bc_off[...], self.bc_len[...] = ext, ext_len, bc_off, bc_len
         return self
 
+    _pending = None          # (engine handle, slot) while a submit_pinned on these arrays has not been waited for
+
     def free(self):
+        """Give the pinned allocation back.  If a submit on these arrays is still in flight its slot is synchronised first:
+        the DMA into hit / ed / end / flags must not land in freed memory."""
         if self._ptr:
+            if self._pending is not None:
+                h, slot = self._pending
+                self._L.bz_slot_sync(h, slot)
+                self._pending = None
             self.ext = self.ext_len = self.bc_off = self.bc_len = self.hit = self.ed = self.end = self.flags = None
             self._L.bz_host_free(self._ptr)
             self._ptr = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:      # noqa: BLE001  (interpreter shutdown: the library may be gone)
+            pass
 
 
 class Engine:
@@ -155,10 +175,12 @@ class Engine:
                                               _ptr(rows.bc_len), rows.n, int(max_ed), _ptr(rows.hit), _ptr(rows.ed), _ptr(rows.end),
                                               _ptr(rows.flags)))
         self._pending[slot] = rows.n
+        rows._pending = (self._h, slot)
 
     def wait_pinned(self, slot, rows: "PinnedRows"):
         check(self._L.bz_assign_wait(self._h, slot, None, None, None, None))
         self._pending[slot] = None
+        rows._pending = None
         return rows.hit, rows.ed, rows.end, rows.flags
 
     # stage / run / fetch, for callers that keep rows resident (bench.py)

@@ -73,12 +73,34 @@ def close_engines():
 
 
 def _ensure_whitelist(eng: Engine, ordered):
-    """Upload `ordered` (a list, order is semantic) unless that exact list is already resident."""
+    """Upload `ordered` (a list, order is semantic) unless that list is already resident: the same object (the usual case, one
+    pointer compare), else a list of the same length whose elements compare equal (a per-row caller that rebuilds its list)."""
     cur = _uploaded.get(eng.device)
-    if cur is not None and (cur is ordered or cur == ordered):
+    if cur is not None and (cur is ordered or (len(cur) == len(ordered) and cur == ordered)):
         return
     eng.set_whitelist(ordered)
     _uploaded[eng.device] = ordered
+
+
+_ordered_of = {}      # id(whitelist container) -> (len, first element, the list made of it): one list per set, not one per row
+
+
+def _ordered_list(whitelist):
+    """The iteration order of `whitelist` as a list.  The reference hands `_match_bc_row` the SAME set for every row of a
+    batch (read_assignment.py:206-211): the list made of it is kept (keyed on the container's identity, its length and its
+    first element) instead of being rebuilt -- and compared with the resident one, 6.8M strings for the full 10x list -- per row."""
+    if isinstance(whitelist, list):
+        return whitelist
+    key = id(whitelist)
+    hit = _ordered_of.get(key)
+    n = len(whitelist)
+    first = next(iter(whitelist)) if n else None
+    if hit is not None and hit[3] is whitelist and hit[0] == n and hit[1] == first:
+        return hit[2]
+    ordered = list(whitelist)
+    _ordered_of.clear()                                  # one container at a time: nothing accumulates
+    _ordered_of[key] = (n, first, ordered, whitelist)     # (holding the container keeps its id from being reused)
+    return ordered
 
 
 # ------------------------------------------------------------------------------ row packing
@@ -182,7 +204,7 @@ def _match_bc_row(row, whitelist, max_ed, minQ, _engine=None):
     if not row.putative_bc or row.putative_bc in whitelist:
         return [row.putative_bc, row.putative_umi, strand]
     eng = _engine or get_engine()
-    ordered = whitelist if isinstance(whitelist, list) else list(whitelist)
+    ordered = _ordered_list(whitelist)
     _ensure_whitelist(eng, ordered)
     ext, ext_len, bc_off, bc_len = _pack_rows([row.putative_bc], [row.putative_umi], [row.pre_bc_flanking])
     hit, _, end, flags = eng.assign(ext, ext_len, bc_off, bc_len, max_ed)

@@ -244,3 +244,32 @@ def test_file_errors_are_also_file_not_found():
         assert isinstance(e, RuntimeError) and "cannot open" in str(e)
     else:
         raise AssertionError("no exception")
+
+
+def test_native_open_errors_carry_errno(tmp_path):
+    """The native open / map failures raise what Python's own open() raises for the same path (ENOENT, EISDIR, EACCES),
+    each also a BlazeHipError, with the errno set."""
+    import ctypes
+    import errno
+    from blaze_amd import _lib
+    L = _lib.load()
+    n = ctypes.c_int64(0)
+
+    def err(path):
+        rc = L.bz_fastq_count_reads(os.fsencode(str(path)), ctypes.byref(n))
+        assert rc < 0
+        with pytest.raises(_lib.BlazeHipError) as ei:
+            _lib.check(rc)
+        return ei.value
+    e = err(tmp_path / "nope.fastq")
+    assert isinstance(e, FileNotFoundError) and e.errno == errno.ENOENT and "cannot open" in str(e)
+    e = err(tmp_path)
+    assert isinstance(e, IsADirectoryError) and e.errno == errno.EISDIR
+    e = err(tmp_path / "nope.fastq.gz")
+    assert isinstance(e, FileNotFoundError)
+    if os.geteuid() != 0:                                  # root opens anything
+        p = tmp_path / "secret.fastq"
+        p.write_text("@a\nA\n+\nI\n")
+        p.chmod(0)
+        e = err(p)
+        assert isinstance(e, PermissionError) and e.errno == errno.EACCES

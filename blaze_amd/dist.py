@@ -518,7 +518,7 @@ def native_run_rank(putative_bc_csv, whitelsit_csv, max_ed, n_process, batchsize
     (host_threads_per_rank).  -> run_rank(fns, out, csv_skip_rows) = (assigned, seen)."""
     from . import read_assignment as ra
 
-    def run_rank(fns, out, csv_skip_rows, csv_byte_offset=None):
+    def run_rank(fns, out, csv_skip_rows, csv_byte_offset=None, on_mismatch="exit"):
         whitelist = []
         with open(whitelsit_csv, 'r') as f:
             for line in f:
@@ -530,8 +530,10 @@ def native_run_rank(putative_bc_csv, whitelsit_csv, max_ed, n_process, batchsize
         threads = host_threads_per_rank(n_process, comm)
         run_rank.host_threads = threads
         return ra._assign_files_native([eng], fns, putative_bc_csv, out, str(out).endswith('.gz'), restrand, max_ed, batchsize,
-                                       ra.DEVICE_BATCH_ROWS, threads, csv_skip_rows=csv_skip_rows or 0, csv_byte_offset=csv_byte_offset)
+                                       ra.DEVICE_BATCH_ROWS, threads, csv_skip_rows=csv_skip_rows or 0, csv_byte_offset=csv_byte_offset,
+                                       on_mismatch=on_mismatch)
     run_rank.takes_byte_offset = True
+    run_rank.can_raise_mismatch = True
     return run_rank
 
 
@@ -573,7 +575,18 @@ def assign_read_sharded(comm, fastq_fns, fastq_out, putative_bc_csv, whitelsit_c
                 break
         found = comm.allreduce_sum_i64(np.array([ok], dtype=np.int64))
         if int(found[0]) == comm.world:
-            sums = run_groups(comm, fastq_out, groups, lambda g, lo, hi, part: run_rank(fastq_fns[lo:hi], part, None, csv_byte_offset=offsets[g]), 2)
+            def run_group(g, lo, hi, part):
+                if not getattr(run_rank, "can_raise_mismatch", False):
+                    return run_rank(fastq_fns[lo:hi], part, None, csv_byte_offset=offsets[g])
+                try:
+                    return run_rank(fastq_fns[lo:hi], part, None, csv_byte_offset=offsets[g], on_mismatch="raise")
+                except ra.OrderMismatch:
+                    # a read id that occurs twice in the job sent the search to the wrong row: this rank counts the reads in
+                    # front of the group instead (its own cost, no collective) -- and if the rows still disagree with the
+                    # reads that is the reference's error (message + sys.exit(), read_assignment.py:219-223)
+                    skip = sum(count_fastq_reads(f) for f in fastq_fns[:lo])
+                    return run_rank(fastq_fns[lo:hi], part, skip)
+            sums = run_groups(comm, fastq_out, groups, run_group, 2)
             return int(sums[0]), int(sums[1])
     mine = np.zeros(comm.world, dtype=np.int64)
     # counting gzipped files means inflating them: the files of this rank side by side (the native counter drops the GIL)

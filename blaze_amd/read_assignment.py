@@ -262,8 +262,13 @@ def _device_ids(devices):
     return list(devices)
 
 
+class OrderMismatch(Exception):
+    """The table's read ids and the FASTQ reads disagree (raised instead of the reference's message + sys.exit() only where
+    the caller has another way to find the rows: dist.assign_read_sharded's located-row route)."""
+
+
 def _assign_files_native(engines, fastq_fns, putative_bc_csv, fastq_out, gz, restrand, max_ed, batchsize,
-                         device_batch_rows, n_threads, csv_skip_rows=0, csv_byte_offset=None):
+                         device_batch_rows, n_threads, csv_skip_rows=0, csv_byte_offset=None, on_mismatch="exit"):
     """bz_assign_files(_from / _at): the C++ host pipeline (blaze_amd/csrc/host_io.h) around the same device scan.
     `csv_skip_rows`: rows of the table that belong to FASTQ files in front of `fastq_fns` (another rank's), or
     `csv_byte_offset`: where this rank's first row starts in the table (dist.locate_first_row)."""
@@ -277,6 +282,8 @@ def _assign_files_native(engines, fastq_fns, putative_bc_csv, fastq_out, gz, res
     rc = entry(handles, len(engines), fns, len(fastq_fns), os.fsencode(str(putative_bc_csv)),
                int(where), os.fsencode(str(fastq_out)), int(bool(gz)), int(bool(restrand)), int(max_ed),
                int(batchsize), int(device_batch_rows), int(n_threads), counts)
+    if rc == _lib.BZ_E_MISMATCH and on_mismatch == "raise":
+        raise OrderMismatch(str(fastq_fns[:1]))
     if rc == _lib.BZ_E_MISMATCH:                    # the reference's reaction, read_assignment.py:219-223
         helper.err_msg("Different order in putative bc file and input fastq!", printit=True)
         sys.exit()

@@ -289,10 +289,11 @@ def _run_sharded(fns, out, kw, world, locate, threads=4):
     device_lock = threading.Lock()
     native = dist.native_run_rank(kw["putative_bc_csv"], kw["whitelsit_csv"], kw["max_ed"], threads, kw["batchsize"], kw["restrand"], 0)
 
-    def run_rank(files, part, skip, csv_byte_offset=None):
+    def run_rank(files, part, skip, **how):
         with device_lock:
-            return native(files, part, skip, csv_byte_offset=csv_byte_offset)
+            return native(files, part, skip, **how)
     run_rank.takes_byte_offset = locate            # True: every rank finds its first row in the table; False: reads are counted
+    run_rank.can_raise_mismatch = True
     res, errs = {}, []
 
     def rank_main(rank):
@@ -454,3 +455,27 @@ def test_rows_wider_than_the_packed_row(tmp_path):
         ra.assign_read(fastq_out=str(tmp_path / "x.fastq"), n_process=4, host="native", **{**kw, "putative_bc_csv": str(too)})
     with pytest.raises(ValueError, match="exceeds the device limit of 64"):
         ra.assign_read(fastq_out=str(tmp_path / "y.fastq"), n_process=1, host="python", **{**kw, "putative_bc_csv": str(too)})
+
+
+def test_sharded_run_with_a_read_id_that_occurs_twice(tmp_path, monkeypatch):
+    """A read id that occurs twice in the job can send a group's row search to the earlier of its rows; the id check then
+    fails at once and the rank counts the reads in front of the group instead: same bytes as the single-process run."""
+    monkeypatch.setenv("BLAZE_AMD_GROUP_MIN_BYTES", "1")
+    n = 3000
+    fns, pc, pw, bounds = _make_files(tmp_path, n, 200, seed=17, n_files=4, quirks=False)
+    # the first read of the third file gets a twin: read 5 of the first file takes its id, in the FASTQ file and in the table
+    lines = open(pc).read().splitlines(keepends=True)
+    twin = lines[1 + bounds[2]].split(",")[0]
+    old = lines[1 + 5].split(",")[0]
+    lines[1 + 5] = twin + lines[1 + 5][len(old):]
+    open(pc, "w").write("".join(lines))
+    fq = open(fns[0]).read()
+    assert fq.count("@" + old + " ") == 1
+    open(fns[0], "w").write(fq.replace("@" + old + " ", "@" + twin + " ").replace("+" + old + "\n", "+\n"))
+    kw = dict(putative_bc_csv=pc, whitelsit_csv=pw, max_ed=2, batchsize=250, restrand=True)
+    whole = str(tmp_path / "whole.fastq")
+    demul, total = ra.assign_read(fastq_fns=fns, fastq_out=whole, n_process=4, host="native", **kw)
+    out = str(tmp_path / "sharded.fastq")
+    res = _run_sharded(fns, out, kw, 3, True)
+    assert all(res[r] == (int(demul), int(total)) for r in range(3)) and int(total) == n
+    assert open(out, "rb").read() == open(whole, "rb").read()

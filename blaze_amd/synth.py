@@ -210,3 +210,78 @@ def write_file_job(d, n, n_cells, umi_len=10, n_files=4, seed=3, median_len=900)
         for w in codes_to_bytes(cells):
             f.write(w.tobytes().decode() + "-1\n")
     return fns, os.path.join(d, "putative_bc.csv"), wl, total_bytes
+
+
+# ---------------------------------------------------------------------------------------------- whole reads (BASELINE configs[0])
+ADAPTOR_FULL = b"CTACACGACGCTCTTCCGATCT"     # 10x read-1 adaptor, ends with config.py:12's CTTCCGATCT
+
+
+def _with_errors(rng, arr, sub, ins, dele):
+    """i.i.d. per-base substitutions / insertions / deletions on a uint8 base array (vectorised)."""
+    n = arr.size
+    if n == 0 or (sub == 0 and ins == 0 and dele == 0):
+        return arr
+    r = rng.random((3, n))
+    arr = np.where(r[0] < sub, _ACGT[rng.integers(0, 4, size=n)], arr)
+    keep = r[1] >= dele
+    extra = keep & (r[2] < ins)
+    reps = keep.astype(np.int64) + extra
+    out = np.repeat(arr, reps)
+    if extra.any():
+        ends = np.cumsum(reps)[extra] - 1              # the second copy of a base that got an insertion behind it
+        out[ends] = _ACGT[rng.integers(0, 4, size=ends.size)]
+    return out
+
+
+_COMP = np.arange(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTacgt", b"TGCAtgca"):
+    _COMP[_a] = _b
+
+
+def write_pipeline_job(d, n_files=29, reads_per_file=4000, n_cells=500, n_full=20000, seed=116):
+    """FASTQ files in the shape of the reference's bundled test run (BASELINE configs[0]: 29 files x 4,000 reads, 3v3 kit;
+    the real files are missing from /root/reference, .MISSING_LARGE_BLOBS:5-33) + a stand-in full whitelist: 80 % of the
+    reads carry one of `n_cells` cell barcodes, 12 % another barcode of the full list, 8 % are junk; nanopore-style errors
+    at three levels; every second read reverse-complemented; noisy qualities.  Deterministic in its arguments.
+    Returns (fastq directory, full whitelist path, sha256 of everything written)."""
+    import hashlib
+    import os
+    rng = np.random.Generator(np.random.PCG64(seed))
+    full = codes_to_bytes(full_whitelist_codes(n_full, seed=seed + 1))
+    cells = full[rng.permutation(n_full)[:n_cells]]
+    weight = rng.gamma(2.0, 1.0, size=n_cells)
+    weight /= weight.sum()                               # cells of different sizes, as a knee plot wants them
+    fq_dir = os.path.join(d, "fastq")
+    os.makedirs(fq_dir, exist_ok=True)
+    digest = hashlib.sha256()
+    errs = [(0.0, 0.0, 0.0), (0.01, 0.005, 0.005), (0.03, 0.01, 0.02)]
+    for f in range(n_files):
+        parts = []
+        for k in range(reads_per_file):
+            u = rng.random()
+            bc = cells[rng.choice(n_cells, p=weight)] if u < 0.80 else full[int(rng.integers(0, n_full))]
+            if u >= 0.92:
+                body = _ACGT[rng.integers(0, 4, size=int(rng.integers(20, 250)))]
+            else:
+                body = np.concatenate([
+                    _ACGT[rng.integers(0, 4, size=int(rng.integers(0, 30)))], np.frombuffer(ADAPTOR_FULL, dtype=np.uint8), bc,
+                    _ACGT[rng.integers(0, 4, size=12)], np.full(int(rng.integers(8, 35)), ord("T"), dtype=np.uint8),
+                    _ACGT[rng.integers(0, 4, size=int(rng.integers(40, 160)))]])
+            seq = _with_errors(rng, body, *errs[k % 3])
+            if seq.size == 0:
+                seq = np.frombuffer(b"A", dtype=np.uint8)
+            if k % 2:
+                seq = _COMP[seq[::-1]]
+            qual = (33 + rng.integers(3 if k % 5 == 0 else 16, 45, size=seq.size)).astype(np.uint8)
+            title = f"@f{f}_r{k}" + (f" runid=x{k} ch=7" if k % 4 == 0 else "")
+            parts.append(title.encode() + b"\n" + seq.tobytes() + b"\n+\n" + qual.tobytes() + b"\n")
+        text = b"".join(parts)
+        digest.update(text)
+        with open(os.path.join(fq_dir, f"reads_{f:02d}.fastq"), "wb") as h:
+            h.write(text)
+    full_fn = os.path.join(d, "full_whitelist.txt")
+    with open(full_fn, "wb") as h:
+        text = b"".join(w.tobytes() + b"\n" for w in full)
+        digest.update(text)
+        h.write(text)
+    return fq_dir, full_fn, digest.hexdigest()

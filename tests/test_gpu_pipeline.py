@@ -182,3 +182,33 @@ def test_multi_rank_main_writes_the_reference_files(tmp_path, monkeypatch, case,
     for key, expect in case["expect"].items():
         assert got[key] == expect, f"{case['name']} / {world} ranks: {key} differs"
     assert not [f for f in os.listdir(os.path.dirname(args.output_fastq)) if ".part" in f]
+
+
+def test_configs0_at_its_stated_size(tmp_path):
+    """BASELINE configs[0] at the size it names: 29 FASTQ files x 4,000 reads, 3v3 kit, --expect-cells 500, all three stages.
+    The fixture (oracle/make_golden_configs0.py) holds what the REAL reference's main() wrote for the same inputs as size,
+    line count and sha256 per output file (the FASTQ output decompressed); the inputs are the deterministic stand-ins of
+    synth.write_pipeline_job (the bundled files are missing from the reference), regenerated here and checked by hash."""
+    import hashlib
+    from blaze_amd import synth
+    with open(os.path.join(os.path.dirname(GOLD), "pipeline_configs0.json")) as f:
+        case = json.load(f)["case"]
+    tmp = str(tmp_path)
+    fq_dir, full_fn, in_sha = synth.write_pipeline_job(tmp, **case["job"])
+    assert in_sha == case["inputs_sha256"], "the generator no longer writes the inputs the reference was run on"
+
+    def sub(v):
+        if isinstance(v, str):
+            return float("inf") if v == "inf" else v.replace("<TMP>", tmp)
+        return [sub(x) for x in v] if isinstance(v, list) else v
+    args = SimpleNamespace(**{k: sub(v) for k, v in case["args"].items()})
+    assert args.full_bc_whitelist == full_fn and len(args.fastq_fns) == 29 and os.path.dirname(args.fastq_fns[0]) == fq_dir
+    os.makedirs(os.path.join(tmp, "out"))
+    bmain.main(args, host="native")
+    for key, exp in case["expect"].items():
+        raw = open(getattr(args, key), "rb").read()
+        if key == "output_fastq" and args.output_fastq.endswith(".gz"):
+            raw = gzip.decompress(raw)
+        got = dict(bytes=len(raw), lines=raw.count(b"\n"), sha256=hashlib.sha256(raw).hexdigest())
+        assert got == exp, f"configs[0]: {key} differs from the reference's file: {got} != {exp}"
+    assert "Total reads: 116000" in open(args.summary_fn).read()

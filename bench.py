@@ -514,6 +514,14 @@ def main():
         eng.sync(0)
         hit, *_ = eng.fetch(0)
         base["gpu_matches_oracle_on_sample"] = bool(np.array_equal(hit[:n_chk], o_hit))
+        # and against the REAL reference: the first 50,000 rows of this very workload went through the real _match_bc_row in
+        # the build container (oracle/make_golden_bench_sample.py -> tests/golden/bench_sample_leftmost.npz, data only)
+        ref_npz = os.path.join(ROOT, "tests", "golden", "bench_sample_leftmost.npz")
+        if os.path.exists(ref_npz) and (a.rows, a.cells, a.max_ed) == (1_000_000, 5000, 2):
+            g = np.load(ref_npz)
+            n_ref = int(g["n_rows"])
+            base["gpu_matches_real_reference_on_sample"] = {"rows": n_ref, "equal": bool(np.array_equal(hit[:n_ref], g["hit"])),
+                                                            "assigned": int((g["hit"] >= 0).sum()), "fixture": "tests/golden/bench_sample_leftmost.npz"}
         # the REAL reference (blaze.read_assignment.assign_read) cannot travel to the GPU box; its figure, measured in the
         # build container by oracle/time_reference.py on 20k reads of this workload's shape, rides along as a quotation
         ref_fn = os.path.join(ROOT, "profiles", "r01f_reference_cpu_B1.json")

@@ -63,7 +63,7 @@ def test_hip_on_config_samples(engine, name):
     def assign(ext, el, bo, bl, wl_ascii):
         engine.set_whitelist_codes16(wl_ascii)
         return engine.assign(ext, el, bo, bl, 2)
-    assert _check(name, assign) > (400 if name == "configs3" else 20_000)
+    assert _check(name, assign) > (300 if name == "configs3" else 20_000)
 
 
 @pytest.mark.gpu

@@ -36,6 +36,10 @@ namespace fqz {
 // polynomials using PCLMULQDQ"; constants for the reflected polynomial 0xEDB88320).  Whole 16-byte chunks of at least 64
 // bytes go through it, the tail through zlib; hosts without PCLMULQDQ use zlib for everything.  Checked against zlib
 // on random lengths in tests/test_host_cpu.py (through bz_gzip_fastq_member: a wrong CRC makes gzip refuse the member).
+// Where the routine's shape comes from: it is the paper's folding scheme laid out the way its public implementations lay it
+// out (Intel's sample code for the paper, and after it zlib-ng's and Chromium zlib's crc32_sse42_simd_: four 128-bit lanes
+// folded by k1|k2, reduced by k3|k4, then k5 and the Barrett step with the same published constants); not from the reference,
+// which has no native code.
 #if defined(__x86_64__)
 __attribute__((target("pclmul,sse4.1"))) inline uint32_t crc32_clmul(const uint8_t *buf, size_t len, uint32_t crc) {   // len >= 64, len % 16 == 0
     alignas(16) static const uint64_t k1k2[2] = {0x0154442bd4ull, 0x01c6e41596ull};

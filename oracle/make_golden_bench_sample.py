@@ -42,14 +42,15 @@ def _rows_and_list():
 
 
 def _work(span):
-    lo, hi = span
+    lo, hi = span[:2]
+    max_ed = span[2] if len(span) > 2 else 2
     if not _state:
         _state["rows"], _state["wl"] = _rows_and_list()
     rows, wl = _state["rows"], _state["wl"]
     ids = [f"r{i}" for i in range(lo, hi)]
     body = synth.csv_text(rows, ["x"] * rows["n"], lo, hi)           # the reference's table text for these rows
     df = pd.read_csv(StringIO(body)).fillna("")
-    return [ra._match_bc_row(row, wl, 2, 0) for row in df.itertuples()]
+    return [ra._match_bc_row(row, wl, max_ed, 0) for row in df.itertuples()]
 
 
 def main():
@@ -69,6 +70,18 @@ def main():
     out = os.path.join(ROOT, "tests", "golden", f"bench_sample_{tag}.npz")
     np.savez_compressed(out, hit=hit, umi=umi, strand=strand, sha256=np.array(sha), n_rows=np.array(N_ROWS), n_cells=np.array(N_CELLS))
     print(tag, "rows", len(res), "assigned", int((hit >= 0).sum()), "sha256", sha[:16], os.path.getsize(out) // 1024, "KiB")
+    if tie == 0:
+        # the same workload at the other --max-edit-distance settings (parser.py:100), first 20,000 rows each
+        arrays = {}
+        n_other = 20_000
+        for max_ed in (0, 1, 3, 4, 6):
+            with Pool(8) as pool:
+                parts = pool.map(_work, [(lo, min(n_other, lo + 1000), max_ed) for lo in range(0, n_other, 1000)])
+            res = [r for p in parts for r in p]
+            arrays[f"ed{max_ed}_hit"] = np.array([pos.get(r[0], -1) if r[0] else -1 for r in res], dtype=np.int32)
+            arrays[f"ed{max_ed}_sha256"] = np.array(hashlib.sha256("".join(f"{r[0]},{r[1]},{r[2]}\n" for r in res).encode()).hexdigest())
+            print("max_ed", max_ed, "rows", len(res), "assigned", int((arrays[f"ed{max_ed}_hit"] >= 0).sum()), flush=True)
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", "bench_sample_max_ed_leftmost.npz"), n_rows=np.array(n_other), **arrays)
 
 
 if __name__ == "__main__":

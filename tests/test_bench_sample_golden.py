@@ -61,3 +61,36 @@ def test_hip_on_the_bench_workload_sample(engine, tag):
         finally:
             engine.set_option(_lib.BZ_OPT_TIE_RULE, 0)
     _check(tag, assign)
+
+
+def _check_max_ed(max_ed, assign):
+    g = np.load(os.path.join(GOLD, "bench_sample_max_ed_leftmost.npz"))
+    n = int(g["n_rows"])
+    w = _workload()
+    rows = w["rows"]
+    ext, el, bo, bl = (a[:n] for a in w["packed"])
+    wl = [x.tobytes().decode() for x in w["wl_ascii"]]
+    hit, _, end, flags = assign(ext, el, bo, bl, wl, max_ed)
+    bad = np.flatnonzero(hit != g[f"ed{max_ed}_hit"])
+    assert bad.size == 0, (max_ed, bad[:5], hit[bad[:5]], g[f"ed{max_ed}_hit"][bad[:5]])
+    s = lambda m, i: m[i].tobytes().decode() if not rows["blank"][i] else ""
+    cols = ([s(rows["bc"], i) for i in range(n)], [s(rows["umi"], i) for i in range(n)], [s(rows["post"], i) for i in range(n)])
+    polyT = [int(rows["polyT_end"][i]) if not rows["blank"][i] else "" for i in range(n)]
+    got = ra._decode_rows(hit, end, flags, el, cols[0], cols[1], cols[2], polyT, wl)
+    text = "".join(f"{b},{u},{st}\n" for b, u, st in got)
+    assert hashlib.sha256(text.encode()).hexdigest() == str(g[f"ed{max_ed}_sha256"]), max_ed
+
+
+@pytest.mark.parametrize("max_ed", [0, 1, 3, 4, 6])
+def test_oracle_on_the_bench_workload_other_max_ed(oracle, max_ed):
+    """--max-edit-distance 0 / 1 / 3 / 4 / 6 (parser.py:100) on the first 20,000 rows, against the real _match_bc_row."""
+    _check_max_ed(max_ed, lambda ext, el, bo, bl, wl, k: oracle.match_rows(ext, el, bo, bl, wl, k, 0, threads=8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_ed", [0, 1, 3, 4, 6])
+def test_hip_on_the_bench_workload_other_max_ed(engine, max_ed):
+    def assign(ext, el, bo, bl, wl, k):
+        engine.set_whitelist_codes16(_workload()["wl_ascii"])
+        return engine.assign(ext, el, bo, bl, k)
+    _check_max_ed(max_ed, assign)

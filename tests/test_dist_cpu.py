@@ -453,6 +453,30 @@ def test_bench_counts_distinct_gpus_not_ranks():
     assert out["n_gpus"] == 2 and out["config"]["shared_gpu_rehearsal"] is False and len(out["config"]["gpu_of_rank"]) == 2
 
 
+def test_bench_under_torch_distributed_run_two_ranks():
+    """The launch form the driver uses for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`), two ranks, stand-in engine: ONE JSON line from rank 0,
+    whole-job value, the launcher named, the hub beside the launcher's own store on MASTER_PORT."""
+    import json
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BLAZE_AMD_BENCH_ENGINE="tests.stub_engine:StubEngine", PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--rows", "4096", "--cells", "64"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_ranks"] == 2 and out["n_gpus_requested"] == 2 and out["scaling"] == "weak"
+    assert out["rows_counted"] == 2 * 3 * 4096 and out["config"]["launcher"].startswith("torchrun")
+    assert abs(out["value"] - 2 * 4096 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+
+
 def test_host_threads_are_split_over_the_ranks_of_a_node(monkeypatch):
     from blaze_amd import dist
     cpus = os.cpu_count() or 1

@@ -847,8 +847,10 @@ __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
 }
 
 constexpr int kVerifyThreads = 256;                               // measured per 293K rows: 128 lanes 37.4 us, 256 35.0, 512 38.6, 1024 50.1
+// (.., 5): five waves per SIMD (91 VGPRs; left alone the compiler takes 97 = four).  A 1M-row step of BASELINE's workload
+// puts 4.5 workgroups on every CU: with four resident the last ones wait for a whole wave-lifetime.
 template <int K>
-__global__ __launch_bounds__(kVerifyThreads) void k_pair_verify(
+__global__ __launch_bounds__(kVerifyThreads, 5) void k_pair_verify(
     const uint32_t *__restrict__ cand, int cap, const uint32_t *__restrict__ cand_cnt,
     const uint32_t *__restrict__ planes32, const uint2 *__restrict__ list_tc,
     const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int tie,
@@ -857,17 +859,28 @@ __global__ __launch_bounds__(kVerifyThreads) void k_pair_verify(
     __shared__ uint32_t events[6][kVerifyThreads];
     __shared__ uint32_t s_cnt[kVerifyThreads], s_bin[64];
     __shared__ uint16_t s_perm[kVerifyThreads];
+    uint32_t (*const s_own)[kVerifyThreads] = events;            // before the rounds: codes (2) + first four candidates of slot tid (see below)
     const int n_list = *n_list_ptr;
     const int tid = threadIdx.x;
     if ((int)(blockIdx.x * blockDim.x) >= n_list) return;         // workgroup-uniform
     // A wave runs as many rounds as its fullest lane: the workgroup's 256 slots are dealt to the lanes in order of
     // their round counts (counting sort in LDS), so each wave holds one quartile; the quartile -> wave map rotates with
     // the workgroup so that no SIMD collects the long waves.
-    int slot;
+    // What a lane needs of its slot at once (codes, the first two rounds' candidates) is requested for slot TID together
+    // with the count, before the sort knows which slot the lane will take, and changes hands through LDS afterwards:
+    // the loads that used to wait for the permutation (one more memory round trip in a kernel that is about one
+    // wave-lifetime long) are in flight while the sort runs.
+    int slot, mine;
     uint32_t cnt_raw;
     {
         const int s0 = blockIdx.x * blockDim.x + tid;
         const uint32_t c = s0 < n_list ? cand_cnt[s0] : 0u;
+        const int s0c = min(s0, n_list - 1);
+        const uint2 t_own = list_tc[s0c];
+        const uint32_t *cp_own = cand + (size_t)(s0c >> 6) * ((size_t)(cap + 1) * 64) + (s0c & 63);
+        uint32_t x_own[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x_own[q] = cp_own[min(q, cap) << 6];   // rows 0..cap of the tile exist (row `cap` = dump)
         s_cnt[tid] = c;
         if (tid < 64) s_bin[tid] = 0;
         __syncthreads();
@@ -883,14 +896,19 @@ __global__ __launch_bounds__(kVerifyThreads) void k_pair_verify(
         }
         __syncthreads();
         s_perm[s_bin[rounds] + pos] = (uint16_t)tid;
+        s_own[0][tid] = t_own.x; s_own[1][tid] = t_own.y;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_own[2 + q][tid] = x_own[q];
         __syncthreads();
-        const int mine = s_perm[(((tid >> 6) + blockIdx.x) & (kVerifyThreads / 64 - 1)) * 64 + (tid & 63)];
+        mine = s_perm[(((tid >> 6) + blockIdx.x) & (kVerifyThreads / 64 - 1)) * 64 + (tid & 63)];
         slot = blockIdx.x * blockDim.x + mine;
         cnt_raw = s_cnt[mine];
     }
     const bool active = slot < n_list;
     const int r = list[active ? slot : n_list - 1];              // only the result stores need it
-    const uint2 t = list_tc[active ? slot : n_list - 1];         // the text's codes + length, from k_classify_packed
+    const uint2 t = make_uint2(s_own[0][mine], s_own[1][mine]);  // the text's codes + length, from k_classify_packed
+    const uint32_t x0 = s_own[2][mine], x1 = s_own[3][mine], x2 = s_own[4][mine], x3 = s_own[5][mine];
+    __syncthreads();                                              // `events` is free again (a wave writes it after its rounds)
     const int len = (int)((t.y >> 8) & 0xFFu);
     bool overflow = cnt_raw == kCandOverflow;
     const uint32_t cnt = overflow ? 0u : cnt_raw;
@@ -925,8 +943,12 @@ __global__ __launch_bounds__(kVerifyThreads) void k_pair_verify(
         a1 = v1 ? x1 : a0;
     };
     uint32_t i0, i1, n0, n1;
-    load_idx(0, i0, i1);
-    load_idx(1, n0, n1);
+    {                                                             // rounds 0 and 1: candidates 0..3, handed over through LDS
+        i0 = 0 < cnt ? x0 : 0u;
+        i1 = 1 < cnt ? x1 : i0;
+        n0 = 2 < cnt ? x2 : 0u;
+        n1 = 3 < cnt ? x3 : n0;
+    }
     uint32_t p0 = planes32[i0], p1 = planes32[i1];
     for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(2 * k < cnt) != 0; ++k) {
         const uint32_t c0 = i0, c1 = i1, q0 = p0, q1 = p1;

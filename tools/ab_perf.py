@@ -1,7 +1,7 @@
 """A/B step time of two builds of libblaze_hip.so on the SAME box (boxes differ by ~15 % in clock):
 alternating child processes, each times the product step (rows resident, one slot) and its kernels.
 
-usage: python tools/ab_perf.py libA.so libB.so [n_rows] [n_cells] [alternations]
+usage: python tools/ab_perf.py libA.so libB.so [n_rows] [n_cells] [alternations]   (or libA.so,libB.so,libC.so,... as ONE argument)
 child: python tools/ab_perf.py --child lib.so n_rows n_cells
 """
 import json
@@ -51,10 +51,13 @@ def child(lib, n_rows, n_cells):
 def main():
     if sys.argv[1] == "--child":
         return child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
-    libs = sys.argv[1:3]
-    n_rows = sys.argv[3] if len(sys.argv) > 3 else "1000000"
-    n_cells = sys.argv[4] if len(sys.argv) > 4 else "5000"
-    alts = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+    if "," in sys.argv[1]:                                       # several builds: libA.so,libB.so,libC.so [n_rows] ...
+        libs, rest = sys.argv[1].split(","), sys.argv[2:]
+    else:
+        libs, rest = sys.argv[1:3], sys.argv[3:]
+    n_rows = rest[0] if len(rest) > 0 else "1000000"
+    n_cells = rest[1] if len(rest) > 1 else "5000"
+    alts = int(rest[2]) if len(rest) > 2 else 3
     res = {lib: [] for lib in libs}
     for _ in range(alts):
         for lib in libs:

@@ -98,6 +98,15 @@ struct Slot {
     uint8_t *h_in = nullptr, *h_out = nullptr;
     int32_t *h_counters = nullptr, *h_counters_dev = nullptr;   // pinned + mapped: the last kernel of a run writes it
     int32_t *d_counters_base = nullptr;   // two sets of 4; d_counters points at the set of the current run
+    // deferred histogram (scan_kernels.h: kPiggyBins): the hits of consecutive runs alternate between two buffers, and a
+    // run whose per-barcode counts have not been taken yet is `pend`ing: the slot's next run carries them along, or
+    // flush_pending() runs them on their own for whoever needs counts, list counters or timings first
+    int32_t *d_hit_buf[2] = {nullptr, nullptr};
+    int hit_cur = 0;
+    bool pend = false;
+    int pend_n = 0;
+    const int32_t *pend_hit = nullptr;
+    int32_t *pend_counters = nullptr;
     bool timed = false;
 };
 
@@ -223,12 +232,13 @@ void free_whitelist(bz_handle h) {
 
 void free_slot(Slot &s) {
     hipFree(s.d_ext); hipFree(s.d_len); hipFree(s.d_off); hipFree(s.d_bcl); hipFree(s.d_flags);
-    hipFree(s.d_hit); hipFree(s.d_fast); hipFree(s.d_gen); hipFree(s.d_redo); hipFree(s.d_fast_tc); hipFree(s.d_ed); hipFree(s.d_end);
+    hipFree(s.d_hit_buf[0]); hipFree(s.d_hit_buf[1]); hipFree(s.d_fast); hipFree(s.d_gen); hipFree(s.d_redo); hipFree(s.d_fast_tc); hipFree(s.d_ed); hipFree(s.d_end);
     hipHostFree(s.h_in); hipHostFree(s.h_out);
     hipFree(s.d_cand); hipFree(s.d_cand_cnt);
     s.d_cand = s.d_cand_cnt = nullptr; s.cand_words = 0; s.cand_stride = 0;
     s.d_ext = s.d_len = s.d_off = s.d_bcl = s.d_flags = nullptr;
-    s.d_hit = s.d_fast = s.d_gen = s.d_redo = nullptr; s.d_fast_tc = nullptr;
+    s.d_hit = s.d_hit_buf[0] = s.d_hit_buf[1] = s.d_fast = s.d_gen = s.d_redo = nullptr; s.d_fast_tc = nullptr;
+    s.hit_cur = 0; s.pend = false;
     s.d_ed = s.d_end = nullptr;
     s.h_in = s.h_out = nullptr;
     s.cap = 0; s.cap_stride = 0;
@@ -287,7 +297,8 @@ int ensure_slot(Slot &s, int64_t n, int stride) {
     HIP_TRY(hipMalloc(&s.d_ext, (size_t)cap * cs));
     HIP_TRY(hipMalloc(&s.d_len, cap)); HIP_TRY(hipMalloc(&s.d_off, cap)); HIP_TRY(hipMalloc(&s.d_bcl, cap));
     HIP_TRY(hipMalloc(&s.d_flags, cap)); HIP_TRY(hipMalloc(&s.d_ed, cap)); HIP_TRY(hipMalloc(&s.d_end, cap));
-    HIP_TRY(hipMalloc(&s.d_hit, cap * 4)); HIP_TRY(hipMalloc(&s.d_fast, cap * 4)); HIP_TRY(hipMalloc(&s.d_gen, cap * 4));
+    HIP_TRY(hipMalloc(&s.d_hit_buf[0], cap * 4)); HIP_TRY(hipMalloc(&s.d_hit_buf[1], cap * 4)); s.d_hit = s.d_hit_buf[0]; s.hit_cur = 0;
+    HIP_TRY(hipMalloc(&s.d_fast, cap * 4)); HIP_TRY(hipMalloc(&s.d_gen, cap * 4));
     HIP_TRY(hipMalloc(&s.d_redo, cap * 4));
     HIP_TRY(hipMalloc(&s.d_fast_tc, cap * 8));
     HIP_TRY(hipHostMalloc(&s.h_in, (size_t)cap * (cs + 3), hipHostMallocDefault));
@@ -383,7 +394,7 @@ bz::GenericArgs generic_args(bz_handle h, const Slot &s) {
 }
 
 // pair-seeded scan, two-kernel form (whitelists whose candidate lists fit `pair_cap` slots per row)
-int launch_pair_two_kernels(bz_handle h, Slot &s) {
+int launch_pair_two_kernels(bz_handle h, Slot &s, int hist_slot, bool piggy, int32_t *publish) {
     const int stride = (int)((s.n + 63) / 64 * 64);
     const int64_t need = (int64_t)(h->pair_cap + 1) * stride;
     if (need > s.cand_words || !s.d_cand_cnt) {
@@ -403,9 +414,13 @@ int launch_pair_two_kernels(bz_handle h, Slot &s) {
         HIP_TRY(hipFuncSetAttribute((const void *)bz::k_pair_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lst_bytes));
         h->cand_lds_set = lst_bytes;
     }
-    hipLaunchKernelGGL(bz::k_pair_candidates, dim3(ga), dim3(bz::kCandWThreads), lst_bytes, s.stream, h->d_pair_bitmap, h->d_pair_tab8,
+    // the pending histogram's second half rides in front of this grid (its first half rode in k_classify_packed's)
+    const uint32_t *const red_partial = piggy ? h->d_hist_partial + (size_t)hist_slot * bz::kHistBlocks * h->n_wl : nullptr;
+    const int red_blocks = piggy ? ((int)h->n_wl + bz::kCandWThreads - 1) / bz::kCandWThreads : 0;
+    hipLaunchKernelGGL(bz::k_pair_candidates, dim3(ga + red_blocks), dim3(bz::kCandWThreads), lst_bytes, s.stream, h->d_pair_bitmap, h->d_pair_tab8,
                        h->d_pair_members, (int)h->n_fast, (const uint2 *)s.d_fast_tc, s.d_counters, s.d_cand, h->pair_cap,
-                       s.d_cand_cnt);
+                       s.d_cand_cnt, red_partial, (int)h->n_wl, h->d_counts, s.pend_counters, publish);
+    if (piggy) s.pend = false;
     if (h->profile) HIP_TRY(hipEventRecord(s.ev[5], s.stream));
     const int block = 256;
     const int grid = (int)((s.n + block - 1) / block);
@@ -451,22 +466,56 @@ int fold_totals(bz_handle h, hipStream_t st) {
     return BZ_OK;
 }
 
+// the slot's pending histogram on its own (nobody to carry it: a reader of counts / counters / timings, or a next run
+// that takes another path)
+int flush_pending(bz_handle h, Slot &s, int hist_slot) {
+    if (!s.pend) return BZ_OK;
+    s.pend = false;
+    uint32_t *const partial = h->d_hist_partial + (size_t)hist_slot * bz::kHistBlocks * h->n_wl;
+    hipLaunchKernelGGL(bz::k_hist_partial, dim3(bz::kHistBlocks), dim3(bz::kHistThreads), (size_t)(h->n_wl + 1) * sizeof(uint32_t), s.stream,
+                       s.pend_hit, s.pend_n, (int)h->n_wl, partial, h->d_counts);
+    hipLaunchKernelGGL(bz::k_hist_reduce, dim3(((int)h->n_wl + 255) / 256), dim3(256), 0, s.stream, partial, (int)h->n_wl, h->d_counts,
+                       s.pend_counters, s.h_counters_dev);
+    HIP_TRY(hipGetLastError());
+    return BZ_OK;
+}
+
+int flush_all(bz_handle h) {
+    for (int i = 0; i < BZ_SLOTS; ++i)
+        if (int rc = flush_pending(h, h->slot[i], i)) return rc;
+    return BZ_OK;
+}
+
 // One run over the rows a Slot (or a Slot-shaped view) describes: classify + shortcut -> scan by max_ed -> byte-wise
 // scan of the irregular rows -> per-barcode counts.  `lists_allowed` = the candidate-list form of the pair-seeded scan and
 // the privatised histogram may be used (both need buffers the engine allocates); without it the scan verifies straight
 // out of the buckets and the counts take global atomics.  The last kernel publishes the list counters to `publish` and
-// zeroes `next_counters`.
-int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed, int32_t *next_counters, int32_t *publish) {
+// zeroes them.  With `may_defer` (the engine's own slots) the counts are left pending for the slot's next run to carry
+// along (Slot::pend), and a pending histogram of the previous run is carried along or flushed here.
+int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed, int32_t *publish, bool may_defer = false) {
     const int n = (int)s.n;
     const bool prof = s.timed;
     const bool packed = bz::packed_stride(s.stride);   // device buffers are hipMalloc'ed (256-byte aligned); bz_assign_device_noalloc checks the caller's
+    // the two-kernel pair-seeded scan is the path that can carry a pending histogram
+    const bool pair2 = h->wl_regular && !h->force_generic && max_ed == 2 && h->scan_mode == 0 && h->n_fast < ((int64_t)1 << 25) && packed &&
+                       h->pair_cap > 0 && !h->pair_fused && lists_allowed;
+    const bool deferrable = may_defer && !prof && h->d_hist_partial && h->n_wl <= bz::kPiggyBins;
+    bool piggy = false;
+    if (s.pend) {
+        if (pair2 && deferrable) piggy = true;
+        else if (int rc = flush_pending(h, s, hist_slot)) return rc;
+    }
     if (prof) HIP_TRY(hipEventRecord(s.ev[0], s.stream));
     {
-        const dim3 cgrid((n + bz::kClassifyThreads * bz::kClassifyRows - 1) / (bz::kClassifyThreads * bz::kClassifyRows));
+        const int cblocks = (n + bz::kClassifyThreads * bz::kClassifyRows - 1) / (bz::kClassifyThreads * bz::kClassifyRows);
+        const dim3 cgrid(cblocks + (piggy ? bz::kHistBlocks : 0));
         if (packed)
-            hipLaunchKernelGGL(bz::k_classify_packed, cgrid, dim3(bz::kClassifyThreads), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
+            hipLaunchKernelGGL(bz::k_classify_packed, cgrid, dim3(bz::kClassifyThreads), piggy ? (size_t)(h->n_wl + 1) * sizeof(uint32_t) : 0, s.stream,
+                               s.d_ext, s.stride, s.d_len, s.d_off,
                                s.d_bcl, n, h->wl_regular, h->d_sorted_pairs, (int)h->n_fast, h->d_bucket, h->d_bucket8, h->bucket_bits, h->shortcut,
-                               h->force_generic, max_ed, s.d_fast, (uint2 *)s.d_fast_tc, s.d_gen, s.d_counters, s.d_hit, s.d_ed, s.d_end, s.d_flags);
+                               h->force_generic, max_ed, s.d_fast, (uint2 *)s.d_fast_tc, s.d_gen, s.d_counters, s.d_hit, s.d_ed, s.d_end, s.d_flags,
+                               piggy ? s.pend_hit : nullptr, s.pend_n, (int)h->n_wl,
+                               piggy ? h->d_hist_partial + (size_t)hist_slot * bz::kHistBlocks * h->n_wl : nullptr, h->d_counts);
         else
             hipLaunchKernelGGL(bz::k_classify, cgrid, dim3(bz::kClassifyThreads), 0, s.stream, s.d_ext, s.stride, s.d_len, s.d_off,
                                s.d_bcl, n, h->wl_regular, h->d_sorted_codes, h->d_sorted_idx, (int)h->n_fast, h->d_bucket, h->bucket_bits, h->shortcut,
@@ -484,7 +533,7 @@ int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed
             case 0: if (seeded) launch_scan_seeded<0>(h, s); else if (filtered) launch_scan_filtered<0>(h, s); else launch_scan<0>(h, s); break;
             case 1: if (seeded) launch_scan_seeded<1>(h, s); else if (filtered) launch_scan_filtered<1>(h, s); else launch_scan<1>(h, s); break;
             case 2: if (seeded && h->scan_mode == 0 && packed) {
-                        if (h->pair_cap > 0 && !h->pair_fused && lists_allowed) { if (int rc = launch_pair_two_kernels(h, s)) return rc; }
+                        if (pair2) { if (int rc = launch_pair_two_kernels(h, s, hist_slot, piggy, publish)) return rc; }
                         else launch_pair_stream(h, s);
                     } else if (seeded) launch_scan_seeded<2>(h, s);
                     else if (filtered) launch_scan_filtered<2>(h, s); else launch_scan<2>(h, s); break;
@@ -534,15 +583,18 @@ int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed
         HIP_TRY(hipGetLastError());
     }
     if (prof) HIP_TRY(hipEventRecord(s.ev[3], s.stream));
-    if (h->d_hist_partial && lists_allowed) {
+    if (piggy && s.pend) return fail(BZ_E_STATE, "a pending histogram was not carried along");   // (pair2 always reaches launch_pair_two_kernels)
+    if (deferrable) {
+        s.pend = true; s.pend_hit = s.d_hit; s.pend_n = n; s.pend_counters = s.d_counters;
+    } else if (h->d_hist_partial && lists_allowed) {
         uint32_t *const partial = h->d_hist_partial + (size_t)hist_slot * bz::kHistBlocks * h->n_wl;
         hipLaunchKernelGGL(bz::k_hist_partial, dim3(bz::kHistBlocks), dim3(bz::kHistThreads), (size_t)(h->n_wl + 1) * sizeof(uint32_t), s.stream,
                            s.d_hit, n, (int)h->n_wl, partial, h->d_counts);
         hipLaunchKernelGGL(bz::k_hist_reduce, dim3(((int)h->n_wl + 255) / 256), dim3(256), 0, s.stream, partial, (int)h->n_wl, h->d_counts,
-                           s.d_counters, next_counters, publish);
+                           s.d_counters, publish);
     } else {
         hipLaunchKernelGGL(bz::k_histogram, dim3(std::min((n + 255) / 256, 1024)), dim3(256), 0, s.stream, s.d_hit, n, (int)h->n_wl, h->d_counts,
-                           s.d_counters, next_counters, publish);
+                           s.d_counters, publish);
     }
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(s.ev[4], s.stream));
@@ -671,6 +723,7 @@ int bz_set_whitelist(bz_handle h, const char *bytes, const int64_t *offsets, int
         // an entry longer than the row is the TEXT of the replaced call and the end index a position inside it: int8 results
         if (offsets[k + 1] - offsets[k] > 127) return fail(BZ_E_LIMIT, "whitelist entry %lld has %lld characters: at most 127", (long long)k, (long long)(offsets[k + 1] - offsets[k]));
     }
+    if (h->n_wl >= 0) { if (int rc = flush_all(h)) return rc; }     // pending counts belong to the list that is about to go (and their list counters must be zeroed)
     HIP_TRY(hipDeviceSynchronize());
     free_whitelist(h);
 
@@ -920,6 +973,7 @@ int bz_assign_stage(bz_handle h, int slot, const uint8_t *ext, int ext_stride, c
     if (ext_stride < 1 || ext_stride > BZ_EXT_MAX) return fail(BZ_E_LIMIT, "ext_stride %d outside 1..%d", ext_stride, BZ_EXT_MAX);
     if (int rc = validate_rows(ext_len, bc_off, bc_len, n, ext_stride)) return rc;
     Slot &s = h->slot[slot];
+    if (n > s.cap || ext_stride > s.cap_stride) { if (int rc = flush_pending(h, s, slot)) return rc; }   // the buffers are about to be replaced
     HIP_TRY(hipStreamSynchronize(s.stream));
     if (int rc = ensure_slot(s, n, ext_stride)) return rc;
     s.n = n; s.stride = ext_stride; s.staged = false; s.ran = false; s.direct_out = false;
@@ -950,9 +1004,11 @@ int bz_assign_run(bz_handle h, int slot, int max_ed) {
     s.timed_pair = false;
     s.tail_done = false;
     if (s.n == 0) { memset(s.h_counters, 0, 4 * sizeof(int32_t)); s.timed = false; s.ran = true; return BZ_OK; }
-    int32_t *const next_counters = s.d_counters_base + (s.d_counters == s.d_counters_base ? 4 : 0);
-    if (int rc = run_rows(h, s, slot, max_ed, /*lists_allowed=*/true, next_counters, s.h_counters_dev)) return rc;
-    s.d_counters = next_counters;
+    // this run's hits and list counters go to the buffers the previous run did NOT use: its histogram may still be pending
+    s.hit_cur ^= 1;
+    s.d_hit = s.d_hit_buf[s.hit_cur];
+    s.d_counters = s.d_counters_base + (s.d_counters == s.d_counters_base ? 4 : 0);
+    if (int rc = run_rows(h, s, slot, max_ed, /*lists_allowed=*/true, s.h_counters_dev, /*may_defer=*/true)) return rc;
     s.ran = true;
     return BZ_OK;
 }
@@ -988,7 +1044,7 @@ int bz_assign_device_noalloc(bz_handle h, const uint8_t *d_ext, int ext_stride, 
     s.d_counters = counters;
     // the array keeps the last call's contents: the list counters must start at zero
     HIP_TRY(hipMemsetAsync(counters, 0, 16 * sizeof(int32_t), s.stream));
-    return run_rows(h, s, 0, max_ed, /*lists_allowed=*/false, counters + 4, counters + 8);
+    return run_rows(h, s, 0, max_ed, /*lists_allowed=*/false, counters + 8);
 }
 
 static int start_fetch(Slot &s) {
@@ -1061,6 +1117,7 @@ int bz_assign_submit_pinned(bz_handle h, int slot, const uint8_t *ext, int ext_s
     }
     if (int rc = validate_rows(ext_len, bc_off, bc_len, n, ext_stride)) return rc;
     Slot &s = h->slot[slot];
+    if (n > s.cap || ext_stride > s.cap_stride) { if (int rc = flush_pending(h, s, slot)) return rc; }   // the buffers are about to be replaced
     HIP_TRY(hipStreamSynchronize(s.stream));
     if (int rc = ensure_slot(s, n, ext_stride)) return rc;
     s.n = n; s.stride = ext_stride; s.staged = false; s.ran = false; s.direct_out = false;
@@ -1092,6 +1149,7 @@ int bz_assign_fetch(bz_handle h, int slot, int32_t *hit, int8_t *ed, int8_t *end
 
 int bz_slot_sync(bz_handle h, int slot) {
     if (int rc = check_slot(h, slot)) return rc;
+    if (int rc = flush_pending(h, h->slot[slot], slot)) return rc;     // "everything submitted to the slot is done" includes its counts
     HIP_TRY(hipStreamSynchronize(h->slot[slot].stream));
     return BZ_OK;
 }
@@ -1100,6 +1158,7 @@ int bz_slot_timing(bz_handle h, int slot, float ms[8], int64_t counts[8]) {
     if (int rc = check_slot(h, slot)) return rc;
     Slot &s = h->slot[slot];
     if (!s.ran) return fail(BZ_E_STATE, "slot %d has not run", slot);
+    if (int rc = flush_pending(h, s, slot)) return rc;                 // the list counters are published by the histogram's last kernel
     HIP_TRY(hipStreamSynchronize(s.stream));
     if (ms) {
         memset(ms, 0, 8 * sizeof(float));
@@ -1262,6 +1321,7 @@ int bz_far_from_all(bz_handle h, const char *a_bytes, const int64_t *a_off, int6
 int bz_counts_reset(bz_handle h) {
     if (int rc = use(h)) return rc;
     if (h->n_wl < 0) return fail(BZ_E_STATE, "no whitelist");
+    if (int rc = flush_all(h)) return rc;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(h->d_counts, 0, counts_bytes(h->n_wl)));
     return BZ_OK;
@@ -1271,6 +1331,7 @@ int bz_counts_get(bz_handle h, int64_t *out, int64_t n_out) {
     if (int rc = use(h)) return rc;
     if (h->n_wl < 0) return fail(BZ_E_STATE, "no whitelist");
     if (!out || n_out != h->n_wl + 2) return fail(BZ_E_ARG, "n_out must be n_whitelist + 2");
+    if (int rc = flush_all(h)) return rc;
     HIP_TRY(hipDeviceSynchronize());
     if (int rc = fold_totals(h, h->slot[0].stream)) return rc;
     HIP_TRY(hipStreamSynchronize(h->slot[0].stream));
@@ -1302,6 +1363,7 @@ int bz_comm_allreduce_counts(bz_handle h) {
     if (int rc = use(h)) return rc;
     if (!h->comm) return fail(BZ_E_STATE, "no communicator");
     if (h->n_wl < 0) return fail(BZ_E_STATE, "no whitelist");
+    if (int rc = flush_all(h)) return rc;
     HIP_TRY(hipDeviceSynchronize());
     hipStream_t st = h->slot[0].stream;
     if (int rc = fold_totals(h, st)) return rc;

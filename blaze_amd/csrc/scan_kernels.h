@@ -691,6 +691,131 @@ constexpr bool pair_probe_ok(int a, int b, int xi, int di) {
     const int u = x < 0 ? -x : 0, v = d < 0 ? -d : d, w = x + d - 4 > 0 ? x + d - 4 : 0;
     return u + v + w <= 2;
 }
+// ------------------------------------------------------------------------------------------
+// Totals: [assigned, rows seen] go to kTotStripes striped slots behind counts[n_wl + 2] (one atomic pair per
+// workgroup) and are folded into counts[n_wl], counts[n_wl+1] by k_fold_totals before anyone reads them.
+// Per-barcode counts of one run.  Two forms:
+//  * whitelists up to kHistLdsBins barcodes: kHistBlocks workgroups each keep a private histogram of ALL bins in LDS
+//    (ds_add, no global atomics), write it to partial[block][bin], and k_hist_reduce adds the partials into counts[]
+//    (one owner per bin).  Global atomics from 8 XCDs on a 40 KB table ran at ~13 G/s = 55 us per 1M rows; this form
+//    takes a pass over hit[] at streaming rate.
+//  * larger whitelists: one global atomic per assigned row (no contention to speak of on millions of bins).
+// Both add [assigned, rows seen] to the striped totals.
+constexpr int kTotStripes = 64;
+constexpr int kHistLdsBins = 32768;
+constexpr int kHistBlocks = 64;
+constexpr int kHistThreads = 1024;
+// A run's per-barcode counts are not needed before somebody asks for them, and the two histogram kernels were 12 us of a
+// 94 us step that does nothing else meanwhile.  The engine therefore DEFERS them (blaze_hip.hip: Slot::pend): the next run
+// on the slot carries them along -- workgroups in front of k_classify_packed's grid take the private histograms of the
+// previous run's hits (its results sit in the slot's other hit buffer), workgroups in front of k_pair_candidates' grid add
+// them into counts[] -- and whoever reads counts, list counters or timings first has the pending histogram run on its own.
+// Whitelists up to kPiggyBins barcodes (the histogram rides in k_classify_packed's dynamic LDS).
+constexpr int kPiggyBins = 12287;
+
+// one workgroup's share of k_hist_partial (kHistThreads threads, (n_wl + 1) words of dynamic LDS)
+__device__ __forceinline__ void hist_partial_block(int block, const int32_t *__restrict__ hit, int n, int n_wl,
+                                                   uint32_t *__restrict__ partial, unsigned long long *__restrict__ counts) {
+    extern __shared__ uint32_t s_bins[];                          // n_wl bins + 1 (assigned)
+    for (int b = threadIdx.x; b <= n_wl; b += kHistThreads) s_bins[b] = 0;
+    __syncthreads();
+    const int per = (((n + kHistBlocks - 1) / kHistBlocks) + 3) & ~3;     // rows per block, multiple of 4 (16-byte loads)
+    const int lo = block * per, hi = min(n, lo + per);
+    int assigned = 0;
+    // four 16-byte loads in flight per thread before their LDS atomics (one after another, a block's 15.6K rows of a 1M-row
+    // step were four dependent load -> atomics rounds per thread)
+    constexpr int kU = 4;
+    for (int i0 = lo + 4 * threadIdx.x; i0 < hi; i0 += kU * 4 * kHistThreads) {
+        int4 h[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int i = i0 + u * 4 * kHistThreads;
+            h[u] = make_int4(-1, -1, -1, -1);
+            if (i + 4 <= hi) h[u] = *(const int4 *)(hit + i);
+            else if (i < hi) {                                    // the block's ragged end (at most once per block)
+                h[u].x = hit[i];
+                if (i + 1 < hi) h[u].y = hit[i + 1];
+                if (i + 2 < hi) h[u].z = hit[i + 2];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            if (h[u].x >= 0) { atomicAdd(&s_bins[h[u].x], 1u); ++assigned; }
+            if (h[u].y >= 0) { atomicAdd(&s_bins[h[u].y], 1u); ++assigned; }
+            if (h[u].z >= 0) { atomicAdd(&s_bins[h[u].z], 1u); ++assigned; }
+            if (h[u].w >= 0) { atomicAdd(&s_bins[h[u].w], 1u); ++assigned; }
+        }
+    }
+    if (assigned) atomicAdd(&s_bins[n_wl], (uint32_t)assigned);
+    __syncthreads();
+    uint32_t *out = partial + (size_t)block * n_wl;
+    for (int b = threadIdx.x; b < n_wl; b += kHistThreads) out[b] = s_bins[b];
+    if (threadIdx.x == 0) {
+        unsigned long long *tot = counts + n_wl + 2 + 2 * (block & (kTotStripes - 1));
+        if (s_bins[n_wl]) atomicAdd(&tot[0], (unsigned long long)s_bins[n_wl]);
+        if (hi > lo) atomicAdd(&tot[1], (unsigned long long)(hi - lo));
+    }
+}
+
+__global__ __launch_bounds__(kHistThreads) void k_hist_partial(const int32_t *__restrict__ hit, int n, int n_wl,
+                                                              uint32_t *__restrict__ partial, unsigned long long *__restrict__ counts) {
+    hist_partial_block((int)blockIdx.x, hit, n, n_wl, partial, counts);
+}
+
+// End-of-run duties of the kernel that finishes a run's histogram: publish the run's list counters to the (host-mapped)
+// pinned buffer the timing call reads, and zero them: the slot's runs alternate between two counter sets, and a set is
+// clean again before the run after next appends to it (so a run needs neither a memset nor a device-to-host copy dispatch).
+__device__ __forceinline__ void finish_run(bool first_block, int32_t *cur, int32_t *host_out) {
+    if (first_block && threadIdx.x < 4) { host_out[threadIdx.x] = cur[threadIdx.x]; cur[threadIdx.x] = 0; }
+}
+
+// bins [first_bin, first_bin + n_threads): the kHistBlocks private histograms added into counts[]
+__device__ __forceinline__ void hist_reduce_bin(int b, const uint32_t *__restrict__ partial, int n_wl, unsigned long long *__restrict__ counts) {
+    if (b >= n_wl) return;
+    unsigned long long s = 0;
+#pragma unroll
+    for (int k0 = 0; k0 < kHistBlocks; k0 += 16) {               // sixteen loads in flight (all 64 cost 130 registers)
+        uint32_t v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = partial[(size_t)(k0 + k) * n_wl + b];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += v[k];
+    }
+    if (s) atomicAdd(&counts[b], s);      // the other slot's run may be adding to the same bin on its own stream
+}
+
+__global__ __launch_bounds__(256) void k_hist_reduce(const uint32_t *__restrict__ partial, int n_wl, unsigned long long *__restrict__ counts,
+                                                    int32_t *cur, int32_t *host_out) {
+    finish_run(blockIdx.x == 0, cur, host_out);
+    hist_reduce_bin((int)(blockIdx.x * blockDim.x + threadIdx.x), partial, n_wl, counts);
+}
+
+__global__ __launch_bounds__(256) void k_histogram(const int32_t *__restrict__ hit, int n, int n_wl,
+                                                  unsigned long long *__restrict__ counts,
+                                                  int32_t *cur, int32_t *host_out) {
+    __shared__ unsigned int s_assigned[4];
+    finish_run(blockIdx.x == 0, cur, host_out);
+    int assigned = 0;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const int h = hit[r];
+        if (h >= 0) { atomicAdd(&counts[h], 1ull); ++assigned; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) assigned += __shfl_down(assigned, o, 64);
+    if ((threadIdx.x & 63) == 0) s_assigned[threadIdx.x >> 6] = (unsigned int)assigned;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long a = (unsigned long long)s_assigned[0] + s_assigned[1] + s_assigned[2] + s_assigned[3];
+        const long long first = (long long)blockIdx.x * blockDim.x;
+        long long rows = 0;                                   // rows this block visited (grid-stride)
+        const long long step = (long long)gridDim.x * blockDim.x;
+        for (long long b = first; b < n; b += step) rows += min((long long)blockDim.x, (long long)n - b);
+        unsigned long long *tot = counts + n_wl + 2 + 2 * (blockIdx.x & (kTotStripes - 1));
+        if (a) atomicAdd(&tot[0], a);
+        if (rows) atomicAdd(&tot[1], (unsigned long long)rows);
+    }
+}
+
 constexpr int kPairBmWords = 2048;                                // 65536 bits per pair
 constexpr int kPairTab = 65537;
 
@@ -728,22 +853,33 @@ constexpr int kCandSeen = 16;                                     // memo entrie
 __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
     const uint32_t *__restrict__ bitmap, const uint2 *__restrict__ tab8, const uint2 *__restrict__ members8, int n_wl,
     const uint2 *__restrict__ list_tc, const int32_t *__restrict__ n_list_ptr,
-    uint32_t *__restrict__ cand, int cap, uint32_t *__restrict__ cand_cnt) {
+    uint32_t *__restrict__ cand, int cap, uint32_t *__restrict__ cand_cnt,
+    const uint32_t *__restrict__ red_partial, int red_n_wl, unsigned long long *__restrict__ red_counts,
+    int32_t *red_cur, int32_t *red_host) {
+    // the deferred histogram of the slot's previous run (see kPiggyBins): red_blocks workgroups in front of the grid add
+    // its private histograms -- k_classify_packed of THIS run took them -- into counts[] and finish that run
+    const int red_blocks = red_partial ? (red_n_wl + kCandWThreads - 1) / kCandWThreads : 0;
+    if ((int)blockIdx.x < red_blocks) {                           // workgroup-uniform
+        finish_run(blockIdx.x == 0, red_cur, red_host);
+        hist_reduce_bin((int)blockIdx.x * kCandWThreads + (int)threadIdx.x, red_partial, red_n_wl, red_counts);
+        return;
+    }
+    const int bid = (int)blockIdx.x - red_blocks, nblk = (int)gridDim.x - red_blocks;
     __shared__ uint32_t bm[kPairCount * kPairBmWords];
     __shared__ uint32_t row_cnt[kCandRowsPerBlock];
     __shared__ uint32_t seen[kCandSeen][kCandRowsPerBlock];       // per row: the last index listed per hash class (bank = row)
     extern __shared__ uint16_t lst[];                             // [cap + 1][128]: the trip's candidate lists (host: n_wl < 65536), row `cap` = dump
     const int n_list = *n_list_ptr;
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x * kCandRowsPerBlock >= n_list) return;    // workgroup-uniform
+    if (bid * kCandRowsPerBlock >= n_list) return;    // workgroup-uniform
     for (int i = tid; i < kPairCount * kPairBmWords / 4; i += kCandWThreads) ((uint4 *)bm)[i] = ((const uint4 *)bitmap)[i];
     const int wave = tid >> 6, lane = tid & 63;
     const int p_mine = wave % kPairCount, rg = wave / kPairCount; // this wave's pair and which 64 rows of the workgroup's 128
     uint32_t *const my_cnt = &row_cnt[rg * 64 + lane];
     // the text's codes come from k_classify_packed (list_tc[slot], one coalesced 8-byte load instead of list -> row);
     // the next trip's are requested a trip ahead
-    uint2 t_next = list_tc[min((int)blockIdx.x * kCandRowsPerBlock + rg * 64 + lane, n_list - 1)];
-    for (int g = blockIdx.x; g * kCandRowsPerBlock < n_list; g += gridDim.x) {      // workgroup-uniform trip count
+    uint2 t_next = list_tc[min(bid * kCandRowsPerBlock + rg * 64 + lane, n_list - 1)];
+    for (int g = bid; g * kCandRowsPerBlock < n_list; g += nblk) {      // workgroup-uniform trip count
         if (tid < kCandRowsPerBlock) row_cnt[tid] = 0;
         for (int i = tid; i < kCandSeen * kCandRowsPerBlock; i += kCandWThreads) (&seen[0][0])[i] = 0xFFFFFFFFu;
         __syncthreads();                                          // bitmaps loaded (first trip), counters cleared
@@ -751,7 +887,7 @@ __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
         const bool active = slot < n_list;
         const uint32_t tlo = t_next.x, thi = t_next.y & 0xFFu;    // 2-bit codes of the text, column j at bits 2j; 'A' padding past
         const uint64_t tc = (uint64_t)tlo | ((uint64_t)thi << 32);   // its end, which can only add candidates
-        t_next = list_tc[min(slot + (int)gridDim.x * kCandRowsPerBlock, n_list - 1)];
+        t_next = list_tc[min(slot + nblk * kCandRowsPerBlock, n_list - 1)];
         uint16_t *const out = lst + rg * 64 + lane;               // the row's column of the trip's lists in LDS
 
         // one bucket entry -> candidate slots (e.x = bucket size (saturating) | offset << 8, e.y = first member)
@@ -1836,7 +1972,6 @@ __global__ void k_pair(const uint8_t *a, int la, const uint8_t *b, int lb, int m
 // `row.putative_bc in whitelist` = look-up of the 2-bit code in the sorted whitelist: a bucket table
 // over the code's top `bucket_bits` bits gives the (short) range, a lower-bound search inside it the
 // entry (duplicates -> first index in caller order).  2-3 dependent loads instead of log2(n_wl).
-constexpr int kTotStripes = 64;
 constexpr int kClassifyRows = 2;                              // rows per thread
 constexpr int kClassifyThreads = 1024;                        // 2048 rows per workgroup and ONE returned list atomic pair for them:
                                                               // same-address returned atomics serialise at ~13 ns each.  Measured per
@@ -1854,7 +1989,17 @@ __global__ __launch_bounds__(kClassifyThreads) void k_classify_packed(
     const uint2 *__restrict__ sorted_pairs, int n_wl, const int32_t *__restrict__ bucket_start, const uint2 *__restrict__ bucket8,
     int bucket_bits, int shortcut, int force_generic, int max_ed, int32_t *__restrict__ fast_list, uint2 *__restrict__ fast_tc,
     int32_t *__restrict__ gen_list, int32_t *__restrict__ counters, int32_t *__restrict__ hit_out,
-    int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
+    int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out,
+    const int32_t *__restrict__ prev_hit, int prev_n, int prev_n_wl, uint32_t *__restrict__ prev_partial,
+    unsigned long long *__restrict__ prev_counts) {
+    // the deferred histogram of the slot's previous run (see kPiggyBins): kHistBlocks workgroups in front of the grid
+    static_assert(kHistThreads == kClassifyThreads, "the histogram workgroups ride in this kernel's grid");
+    const int hist_blocks = prev_hit ? kHistBlocks : 0;
+    if ((int)blockIdx.x < hist_blocks) {                      // workgroup-uniform
+        hist_partial_block((int)blockIdx.x, prev_hit, prev_n, prev_n_wl, prev_partial, prev_counts);
+        return;
+    }
+    const int bid = (int)blockIdx.x - hist_blocks;
     __shared__ int s_cnt[2][kClassifyRows][kClassifyWaves];   // [list][k][wave] -> exclusive offsets
     __shared__ int s_base[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1864,7 +2009,7 @@ __global__ __launch_bounds__(kClassifyThreads) void k_classify_packed(
     uint32_t bad_row[kClassifyRows];                          // flags of a row without a barcode: blank, or blank | invalid
 #pragma unroll
     for (int k = 0; k < kClassifyRows; ++k) {
-        r[k] = (blockIdx.x * kClassifyRows + k) * kClassifyThreads + threadIdx.x;
+        r[k] = (bid * kClassifyRows + k) * kClassifyThreads + threadIdx.x;
         in[k] = r[k] < n;
         const int rr = in[k] ? r[k] : 0;
         len[k] = ext_len[rr]; off[k] = bc_off[rr]; bl[k] = bc_len[rr];
@@ -2073,109 +2218,7 @@ __global__ __launch_bounds__(kClassifyThreads) void k_classify(
     }
 }
 
-// Totals: [assigned, rows seen] go to kTotStripes striped slots behind counts[n_wl + 2] (one atomic pair per
-// workgroup) and are folded into counts[n_wl], counts[n_wl+1] by k_fold_totals before anyone reads them.
-// Per-barcode counts of one run.  Two forms:
-//  * whitelists up to kHistLdsBins barcodes: kHistBlocks workgroups each keep a private histogram of ALL bins in LDS
-//    (ds_add, no global atomics), write it to partial[block][bin], and k_hist_reduce adds the partials into counts[]
-//    (one owner per bin).  Global atomics from 8 XCDs on a 40 KB table ran at ~13 G/s = 55 us per 1M rows; this form
-//    takes a pass over hit[] at streaming rate.
-//  * larger whitelists: one global atomic per assigned row (no contention to speak of on millions of bins).
-// Both add [assigned, rows seen] to the striped totals.
-constexpr int kHistLdsBins = 32768;
-constexpr int kHistBlocks = 64;
-constexpr int kHistThreads = 1024;
-
-__global__ __launch_bounds__(kHistThreads) void k_hist_partial(const int32_t *__restrict__ hit, int n, int n_wl,
-                                                              uint32_t *__restrict__ partial, unsigned long long *__restrict__ counts) {
-    extern __shared__ uint32_t s_bins[];                          // n_wl bins + 1 (assigned)
-    for (int b = threadIdx.x; b <= n_wl; b += kHistThreads) s_bins[b] = 0;
-    __syncthreads();
-    const int per = (((n + kHistBlocks - 1) / kHistBlocks) + 3) & ~3;     // rows per block, multiple of 4 (16-byte loads)
-    const int lo = blockIdx.x * per, hi = min(n, lo + per);
-    int assigned = 0;
-    // four 16-byte loads in flight per thread before their LDS atomics (one after another, a block's 15.6K rows of a 1M-row
-    // step were four dependent load -> atomics rounds per thread)
-    constexpr int kU = 4;
-    for (int i0 = lo + 4 * threadIdx.x; i0 < hi; i0 += kU * 4 * kHistThreads) {
-        int4 h[kU];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const int i = i0 + u * 4 * kHistThreads;
-            h[u] = make_int4(-1, -1, -1, -1);
-            if (i + 4 <= hi) h[u] = *(const int4 *)(hit + i);
-            else if (i < hi) {                                    // the block's ragged end (at most once per block)
-                h[u].x = hit[i];
-                if (i + 1 < hi) h[u].y = hit[i + 1];
-                if (i + 2 < hi) h[u].z = hit[i + 2];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            if (h[u].x >= 0) { atomicAdd(&s_bins[h[u].x], 1u); ++assigned; }
-            if (h[u].y >= 0) { atomicAdd(&s_bins[h[u].y], 1u); ++assigned; }
-            if (h[u].z >= 0) { atomicAdd(&s_bins[h[u].z], 1u); ++assigned; }
-            if (h[u].w >= 0) { atomicAdd(&s_bins[h[u].w], 1u); ++assigned; }
-        }
-    }
-    if (assigned) atomicAdd(&s_bins[n_wl], (uint32_t)assigned);
-    __syncthreads();
-    uint32_t *out = partial + (size_t)blockIdx.x * n_wl;
-    for (int b = threadIdx.x; b < n_wl; b += kHistThreads) out[b] = s_bins[b];
-    if (threadIdx.x == 0) {
-        unsigned long long *tot = counts + n_wl + 2 + 2 * (blockIdx.x & (kTotStripes - 1));
-        if (s_bins[n_wl]) atomicAdd(&tot[0], (unsigned long long)s_bins[n_wl]);
-        if (hi > lo) atomicAdd(&tot[1], (unsigned long long)(hi - lo));
-    }
-}
-
-// End-of-run duties of the last kernel of a run: publish the run's list counters to the (host-mapped) pinned
-// buffer the timing call reads, and zero the OTHER counter set, which the next run on this slot will use
-// (so a run needs neither a memset nor a device-to-host copy dispatch).
-__device__ __forceinline__ void finish_run(const int32_t *cur, int32_t *next, int32_t *host_out) {
-    if (blockIdx.x == 0 && threadIdx.x < 4) { host_out[threadIdx.x] = cur[threadIdx.x]; next[threadIdx.x] = 0; }
-}
-
-__global__ __launch_bounds__(256) void k_hist_reduce(const uint32_t *__restrict__ partial, int n_wl, unsigned long long *__restrict__ counts,
-                                                    const int32_t *cur, int32_t *next, int32_t *host_out) {
-    finish_run(cur, next, host_out);
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_wl) return;
-    uint32_t v[kHistBlocks];
-#pragma unroll
-    for (int k = 0; k < kHistBlocks; ++k) v[k] = partial[(size_t)k * n_wl + b];   // all loads in flight: one latency
-    unsigned long long s = 0;
-#pragma unroll
-    for (int k = 0; k < kHistBlocks; ++k) s += v[k];
-    if (s) atomicAdd(&counts[b], s);      // the other slot's run may be adding to the same bin on its own stream
-}
-
-__global__ __launch_bounds__(256) void k_histogram(const int32_t *__restrict__ hit, int n, int n_wl,
-                                                  unsigned long long *__restrict__ counts,
-                                                  const int32_t *cur, int32_t *next, int32_t *host_out) {
-    __shared__ unsigned int s_assigned[4];
-    finish_run(cur, next, host_out);
-    int assigned = 0;
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        const int h = hit[r];
-        if (h >= 0) { atomicAdd(&counts[h], 1ull); ++assigned; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) assigned += __shfl_down(assigned, o, 64);
-    if ((threadIdx.x & 63) == 0) s_assigned[threadIdx.x >> 6] = (unsigned int)assigned;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long a = (unsigned long long)s_assigned[0] + s_assigned[1] + s_assigned[2] + s_assigned[3];
-        const long long first = (long long)blockIdx.x * blockDim.x;
-        long long rows = 0;                                   // rows this block visited (grid-stride)
-        const long long step = (long long)gridDim.x * blockDim.x;
-        for (long long b = first; b < n; b += step) rows += min((long long)blockDim.x, (long long)n - b);
-        unsigned long long *tot = counts + n_wl + 2 + 2 * (blockIdx.x & (kTotStripes - 1));
-        if (a) atomicAdd(&tot[0], a);
-        if (rows) atomicAdd(&tot[1], (unsigned long long)rows);
-    }
-}
-
+// the striped totals folded (see the histogram kernels)
 __global__ void k_fold_totals(unsigned long long *__restrict__ counts, int n_wl) {
     if (blockIdx.x != 0 || threadIdx.x >= 2) return;
     unsigned long long s = 0;

@@ -255,7 +255,10 @@ int bz_putative_bc_files(bz_handle *engines, int n_engines, const char *const *f
 /* ---- per-barcode counts + the one collective -------------------------------------------- */
 /* Device-resident int64 histogram counts[0..n_wl) of assigned rows per barcode, followed by
  * counts[n_wl] = rows assigned, counts[n_wl+1] = rows seen (the two scalars the reference sums
- * at read_assignment.py:299-301,324-326).  Every bz_assign_run adds to it. */
+ * at read_assignment.py:299-301,324-326).  Every bz_assign_run adds to it -- not necessarily before it returns control to
+ * the stream's next kernel: the counts of a slot's last run may ride along with the slot's next run (two short kernels
+ * less per step); bz_counts_get / bz_counts_reset / bz_comm_allreduce_counts / bz_slot_sync / bz_slot_timing and
+ * bz_set_whitelist run whatever is still pending first, so every reader sees every run counted exactly once. */
 int bz_counts_reset(bz_handle h);
 int bz_counts_get(bz_handle h, int64_t *out, int64_t n_out);     /* n_out = n_wl + 2 */
 /* RCCL over xGMI, one process per GPU: rank 0 makes the id, the host passes it round,

@@ -866,23 +866,32 @@ __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
     }
     const int bid = (int)blockIdx.x - red_blocks, nblk = (int)gridDim.x - red_blocks;
     __shared__ uint32_t bm[kPairCount * kPairBmWords];
-    __shared__ uint32_t row_cnt[kCandRowsPerBlock];
-    __shared__ uint32_t seen[kCandSeen][kCandRowsPerBlock];       // per row: the last index listed per hash class (bank = row)
+    __shared__ uint32_t row_cnt[2][kCandRowsPerBlock];            // by trip parity: a trip's counters are cleared while the trip before it writes out
+    __shared__ uint32_t seen[kCandSeen][kCandRowsPerBlock];       // per row: the last index listed per hash class (bank = row), tagged with the trip
     extern __shared__ uint16_t lst[];                             // [cap + 1][128]: the trip's candidate lists (host: n_wl < 65536), row `cap` = dump
     const int n_list = *n_list_ptr;
     const int tid = threadIdx.x;
     if (bid * kCandRowsPerBlock >= n_list) return;    // workgroup-uniform
     for (int i = tid; i < kPairCount * kPairBmWords / 4; i += kCandWThreads) ((uint4 *)bm)[i] = ((const uint4 *)bitmap)[i];
+    if (tid < 2 * kCandRowsPerBlock) (&row_cnt[0][0])[tid] = 0;
+    for (int i = tid; i < kCandSeen * kCandRowsPerBlock; i += kCandWThreads) (&seen[0][0])[i] = 0xFFFFFFFFu;
+    __syncthreads();                                              // bitmaps loaded, counters and memo cleared
     const int wave = tid >> 6, lane = tid & 63;
     const int p_mine = wave % kPairCount, rg = wave / kPairCount; // this wave's pair and which 64 rows of the workgroup's 128
-    uint32_t *const my_cnt = &row_cnt[rg * 64 + lane];
+    uint32_t trip = 0;
     // the text's codes come from k_classify_packed (list_tc[slot], one coalesced 8-byte load instead of list -> row);
     // the next trip's are requested a trip ahead
     uint2 t_next = list_tc[min(bid * kCandRowsPerBlock + rg * 64 + lane, n_list - 1)];
-    for (int g = bid; g * kCandRowsPerBlock < n_list; g += nblk) {      // workgroup-uniform trip count
-        if (tid < kCandRowsPerBlock) row_cnt[tid] = 0;
-        for (int i = tid; i < kCandSeen * kCandRowsPerBlock; i += kCandWThreads) (&seen[0][0])[i] = 0xFFFFFFFFu;
-        __syncthreads();                                          // bitmaps loaded (first trip), counters cleared
+    for (int g = bid; g * kCandRowsPerBlock < n_list; g += nblk, ++trip) {      // workgroup-uniform trip count
+        // The memo is never cleared between trips: an entry carries the trip that wrote it in its upper half (indices
+        // are below 65536), so what an earlier trip left cannot match.  (Cleared again before the tag could repeat.)
+        if ((trip & 0x7FFFu) == 0x7FFFu) {                        // workgroup-uniform, every 32K trips of a workgroup
+            __syncthreads();
+            for (int i = tid; i < kCandSeen * kCandRowsPerBlock; i += kCandWThreads) (&seen[0][0])[i] = 0xFFFFFFFFu;
+            __syncthreads();
+        }
+        const uint32_t tag = (trip & 0x7FFFu) << 16;
+        uint32_t *const my_cnt = &row_cnt[trip & 1u][rg * 64 + lane];
         const int slot = g * kCandRowsPerBlock + rg * 64 + lane;
         const bool active = slot < n_list;
         const uint32_t tlo = t_next.x, thi = t_next.y & 0xFFu;    // 2-bit codes of the text, column j at bits 2j; 'A' padding past
@@ -897,7 +906,7 @@ __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
         // k_pair_verify ignores an index it already keeps).  ~14 -> ~10 candidates per row of a 5k-cell list.
         auto emit = [&](uint32_t idx) {
             uint32_t *const sp = &seen[idx & (kCandSeen - 1)][rg * 64 + lane];
-            if (atomicExch(sp, idx) == idx) return;              // one LDS exchange: of two waves listing an index at the same moment one sees the other's
+            if (atomicExch(sp, tag | idx) == (tag | idx)) return;  // one LDS exchange: of two waves listing an index at the same moment one sees the other's
             const uint32_t base = atomicAdd(my_cnt, 1u);
             out[min(base, (uint32_t)cap) * kCandRowsPerBlock] = (uint16_t)idx;  // row `cap` is a dump row
         };
@@ -971,7 +980,8 @@ __global__ __launch_bounds__(kCandWThreads) void k_pair_candidates(
         // Wave w takes rows w / 2, w / 2 + 6, ... of tile w % 2.
         {
             const int t = wave & 1, row = t * 64 + lane, wslot = g * kCandRowsPerBlock + row;
-            const uint32_t c = row_cnt[row];
+            const uint32_t c = row_cnt[trip & 1u][row];
+            if (tid < kCandRowsPerBlock) row_cnt[(trip & 1u) ^ 1u][tid] = 0;   // the next trip's counters (last read before this trip's first barrier)
             const uint32_t c_ok = (wslot < n_list && c <= (uint32_t)cap) ? c : 0u;
             uint32_t *const tile = cand + (size_t)(wslot >> 6) * ((size_t)(cap + 1) * 64) + lane;
             for (uint32_t q = (uint32_t)(wave >> 1); __builtin_amdgcn_ballot_w64(q < c_ok) != 0; q += kCandWaves / 2)
@@ -992,10 +1002,9 @@ __global__ __launch_bounds__(kVerifyThreads, 5) void k_pair_verify(
     const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int tie,
     int32_t *__restrict__ redo_list, int32_t *__restrict__ n_redo,
     int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
-    __shared__ uint32_t events[6][kVerifyThreads];
+    __shared__ uint32_t s_own[6][kVerifyThreads];                 // codes (2) + first four candidates of slot tid (see below)
     __shared__ uint32_t s_cnt[kVerifyThreads], s_bin[64];
     __shared__ uint16_t s_perm[kVerifyThreads];
-    uint32_t (*const s_own)[kVerifyThreads] = events;            // before the rounds: codes (2) + first four candidates of slot tid (see below)
     const int n_list = *n_list_ptr;
     const int tid = threadIdx.x;
     if ((int)(blockIdx.x * blockDim.x) >= n_list) return;         // workgroup-uniform
@@ -1044,7 +1053,6 @@ __global__ __launch_bounds__(kVerifyThreads, 5) void k_pair_verify(
     const int r = list[active ? slot : n_list - 1];              // only the result stores need it
     const uint2 t = make_uint2(s_own[0][mine], s_own[1][mine]);  // the text's codes + length, from k_classify_packed
     const uint32_t x0 = s_own[2][mine], x1 = s_own[3][mine], x2 = s_own[4][mine], x3 = s_own[5][mine];
-    __syncthreads();                                              // `events` is free again (a wave writes it after its rounds)
     const int len = (int)((t.y >> 8) & 0xFFu);
     bool overflow = cnt_raw == kCandOverflow;
     const uint32_t cnt = overflow ? 0u : cnt_raw;
@@ -1138,47 +1146,56 @@ __global__ __launch_bounds__(kVerifyThreads, 5) void k_pair_verify(
     // any column = the minimum over all end positions), and the fold needs the end index of the WINNER only: the kept
     // indices become events as they are and one exact pass after the fold gives the winner's end.  (Every kept barcode
     // used to get its exact (ed, end) first: as many wave-wide passes as the fullest lane kept, ~2.5 per wave.)  Shorter
-    // texts keep that path: their pool has no classes.
-    int nkept = 0, nacc = 0;
+    // texts keep that path: their pool has no classes, only slots 4 and 5 (class 2) are in use.
+    // The at most six events (index << 7 | ed << 5 | end; 0xFFFFFFFF = none) stay in registers: a fixed sorting network
+    // and an unrolled fold instead of an insertion sort over per-lane LDS columns.
+    uint32_t ev[6];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (keep[c][t] == 0xFFFFFFFFu) continue;
-            if (full_text) events[nacc++][tid] = (keep[c][t] << 7) | ((uint32_t)c << 5);
-            else events[nkept++][tid] = keep[c][t];
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t idx = keep[c][q];
+            ev[2 * c + q] = idx == 0xFFFFFFFFu ? 0xFFFFFFFFu : full_text ? ((idx << 7) | ((uint32_t)c << 5)) : idx;
         }
     }
-    for (int a = 0; __builtin_amdgcn_ballot_w64(a < nkept) != 0; ++a) {
-        if (a < nkept) {
-            const uint32_t idx = events[a][tid];
-            const uint32_t p = planes32[idx];
+    if (__builtin_amdgcn_ballot_w64(!full_text && active && !overflow) != 0) {
+#pragma unroll 1
+        for (int a = 4; a < 6; ++a) {
+            const uint32_t idx = a == 4 ? ev[4] : ev[5];
+            const bool want = !full_text && idx != 0xFFFFFFFFu;
+            if (__builtin_amdgcn_ballot_w64(want) == 0) continue;
+            const uint32_t p = planes32[want ? idx : 0u];
             int ed, end;
             exact_pair<K>(p & 0xFFFFu, p >> 16, XH, XL, len, tie, ed, end);
-            if (ed <= K) events[nacc++][tid] = (idx << 7) | ((uint32_t)ed << 5) | (uint32_t)end;   // nacc <= a: in place
+            const uint32_t v = (want && ed <= K) ? ((idx << 7) | ((uint32_t)ed << 5) | (uint32_t)end) : 0xFFFFFFFFu;
+            if (!full_text) { if (a == 4) ev[4] = v; else ev[5] = v; }
         }
+    }
+    // whitelist order: the 12-comparator network for six inputs (none sorts last)
+    auto cx = [&](uint32_t &a, uint32_t &b) { const uint32_t lo = min(a, b), hi = max(a, b); a = lo; b = hi; };
+    cx(ev[0], ev[5]); cx(ev[1], ev[3]); cx(ev[2], ev[4]);
+    cx(ev[1], ev[2]); cx(ev[3], ev[4]);
+    cx(ev[0], ev[3]); cx(ev[2], ev[5]);
+    cx(ev[0], ev[1]); cx(ev[2], ev[3]); cx(ev[4], ev[5]);
+    cx(ev[1], ev[2]); cx(ev[3], ev[4]);
+    int best = K, hit = kHitNone, hit_end = -1;
+    bool done = false;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const uint32_t v = ev[a];
+        if (v != 0xFFFFFFFFu) fold_update((int)((v >> 5) & 3u), (int)(v & 31u), (int)(v >> 7), best, hit, hit_end, done);
+    }
+    if (__builtin_amdgcn_ballot_w64(full_text && hit >= 0 && active && !overflow) != 0) {     // the winner's end index (its ed is `best`)
+        const bool want = full_text && hit >= 0;
+        const uint32_t p = planes32[want ? hit : 0];
+        int ed_w, end_w;
+        exact_pair<K>(p & 0xFFFFu, p >> 16, XH, XL, len, tie, ed_w, end_w);
+        if (want) hit_end = end_w;
     }
     if (!active) return;
     if (overflow) {                                               // too many candidates / near matches: finish in whitelist order
         redo_list[atomicAdd(n_redo, 1)] = r;
         return;
-    }
-    for (int a = 1; a < nacc; ++a) {                              // events in whitelist order (insertion sort)
-        const uint32_t v = events[a][tid];
-        int b = a - 1;
-        while (b >= 0 && events[b][tid] > v) { events[b + 1][tid] = events[b][tid]; --b; }
-        events[b + 1][tid] = v;
-    }
-    int best = K, hit = kHitNone, hit_end = -1;
-    bool done = false;
-    for (int a = 0; a < nacc; ++a) {
-        const uint32_t v = events[a][tid];
-        fold_update((int)((v >> 5) & 3u), (int)(v & 31u), (int)(v >> 7), best, hit, hit_end, done);
-    }
-    if (full_text && hit >= 0) {                                  // the winner's end index (its ed is `best`)
-        const uint32_t p = planes32[hit];
-        int ed_w;
-        exact_pair<K>(p & 0xFFFFu, p >> 16, XH, XL, len, tie, ed_w, hit_end);
     }
     hit_out[r] = hit >= 0 ? hit : -1;
     ed_out[r] = (int8_t)best;

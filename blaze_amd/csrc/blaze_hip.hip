@@ -371,13 +371,17 @@ void launch_scan_filtered(bz_handle h, Slot &s) {
 // seeded scan over fast_list (single-piece seeds); every row is finished here: the lane keeps the two smallest events per
 // distance class, which is all the fold consumes, so nothing is handed to the ordered scan any more
 template <int K>
-void launch_scan_seeded(bz_handle h, Slot &s) {
+void launch_scan_seeded(bz_handle h, Slot &s, int hist_slot, bool piggy, int32_t *publish) {
     const int block = 256;
     const int grid = (int)((s.n + block - 1) / block);
     const int plan = K == 2 ? 0 : K == 3 ? 2 : 1;
-    hipLaunchKernelGGL(bz::k_scan_seeded<K>, dim3(grid), dim3(block), 0, s.stream, h->d_seed_tab[plan], h->d_seed_members[plan],
+    // the pending histogram's second half rides in front of this grid (its first half rode in k_classify_packed's)
+    const uint32_t *const red_partial = piggy ? h->d_hist_partial + (size_t)hist_slot * bz::kHistBlocks * h->n_wl : nullptr;
+    const int red_blocks = piggy ? ((int)h->n_wl + block - 1) / block : 0;
+    hipLaunchKernelGGL(bz::k_scan_seeded<K>, dim3(grid + red_blocks), dim3(block), 0, s.stream, h->d_seed_tab[plan], h->d_seed_members[plan],
                        h->d_planes32, (int)h->n_fast, s.d_ext, s.stride, s.d_len, s.d_fast, s.d_counters, h->tie_rule,
-                       s.d_hit, s.d_ed, s.d_end, s.d_flags);
+                       s.d_hit, s.d_ed, s.d_end, s.d_flags, red_partial, (int)h->n_wl, h->d_counts, s.pend_counters, publish);
+    if (piggy) s.pend = false;
 }
 
 // what the workgroup-per-row scan of the irregular rows needs (scan_kernels.h: generic_row_wg)
@@ -496,13 +500,17 @@ int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed
     const int n = (int)s.n;
     const bool prof = s.timed;
     const bool packed = bz::packed_stride(s.stride);   // device buffers are hipMalloc'ed (256-byte aligned); bz_assign_device_noalloc checks the caller's
-    // the two-kernel pair-seeded scan is the path that can carry a pending histogram
-    const bool pair2 = h->wl_regular && !h->force_generic && max_ed == 2 && h->scan_mode == 0 && h->n_fast < ((int64_t)1 << 25) && packed &&
-                       h->pair_cap > 0 && !h->pair_fused && lists_allowed;
+    // the paths that can carry a pending histogram: k_classify_packed takes its first half, the second rides in front of
+    // k_pair_candidates' grid (the two-kernel pair-seeded scan) or k_scan_seeded's (max_ed 0, 1, 3; scan mode 3)
+    const bool regular_path = h->wl_regular && !h->force_generic && max_ed <= bz::kMaxK;
+    const bool seeded = (h->scan_mode == 0 || h->scan_mode == 3) && h->n_fast < ((int64_t)1 << 25);
+    const bool pair_path = regular_path && seeded && max_ed == 2 && h->scan_mode == 0 && packed;      // pair seeds: lists + verify, or straight out of the buckets
+    const bool pair2 = pair_path && h->pair_cap > 0 && !h->pair_fused && lists_allowed;
+    const bool seeded_kernel = regular_path && seeded && max_ed <= 3 && !pair_path;                  // k_scan_seeded<max_ed>
     const bool deferrable = may_defer && !prof && h->d_hist_partial && h->n_wl <= bz::kPiggyBins;
     bool piggy = false;
     if (s.pend) {
-        if (pair2 && deferrable) piggy = true;
+        if ((pair2 || seeded_kernel) && packed && deferrable) piggy = true;
         else if (int rc = flush_pending(h, s, hist_slot)) return rc;
     }
     if (prof) HIP_TRY(hipEventRecord(s.ev[0], s.stream));
@@ -527,17 +535,16 @@ int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed
         // product path: pigeonhole seeds + verify (BZ_OPT_SCAN_MODE 0; max_ed 3: four 4-nt pieces); mode 2 = exact 3-gram
         // filter + verify over the whole whitelist (max_ed <= 2; its sets are too weak for 3); mode 1 = brute force
         // (event words hold the barcode index in 25 bits: larger whitelists take the filtered scan)
-        const bool seeded = (h->scan_mode == 0 || h->scan_mode == 3) && h->n_fast < ((int64_t)1 << 25);
         const bool filtered = !seeded && h->scan_mode != 1 && max_ed <= 2;
         switch (max_ed) {
-            case 0: if (seeded) launch_scan_seeded<0>(h, s); else if (filtered) launch_scan_filtered<0>(h, s); else launch_scan<0>(h, s); break;
-            case 1: if (seeded) launch_scan_seeded<1>(h, s); else if (filtered) launch_scan_filtered<1>(h, s); else launch_scan<1>(h, s); break;
-            case 2: if (seeded && h->scan_mode == 0 && packed) {
+            case 0: if (seeded) launch_scan_seeded<0>(h, s, hist_slot, piggy, publish); else if (filtered) launch_scan_filtered<0>(h, s); else launch_scan<0>(h, s); break;
+            case 1: if (seeded) launch_scan_seeded<1>(h, s, hist_slot, piggy, publish); else if (filtered) launch_scan_filtered<1>(h, s); else launch_scan<1>(h, s); break;
+            case 2: if (pair_path) {
                         if (pair2) { if (int rc = launch_pair_two_kernels(h, s, hist_slot, piggy, publish)) return rc; }
                         else launch_pair_stream(h, s);
-                    } else if (seeded) launch_scan_seeded<2>(h, s);
+                    } else if (seeded) launch_scan_seeded<2>(h, s, hist_slot, piggy, publish);
                     else if (filtered) launch_scan_filtered<2>(h, s); else launch_scan<2>(h, s); break;
-            case 3: if (seeded) launch_scan_seeded<3>(h, s); else launch_scan<3>(h, s); break;
+            case 3: if (seeded) launch_scan_seeded<3>(h, s, hist_slot, piggy, publish); else launch_scan<3>(h, s); break;
             // above 3 no seed plan is exact any more (a 16-mer has no piece that survives 4 edits): every pair through the
             // packed automaton, 40 (1 + K) instructions per pair
             case 4: launch_scan<4>(h, s); break;
@@ -583,7 +590,7 @@ int run_rows(bz_handle h, Slot &s, int hist_slot, int max_ed, bool lists_allowed
         HIP_TRY(hipGetLastError());
     }
     if (prof) HIP_TRY(hipEventRecord(s.ev[3], s.stream));
-    if (piggy && s.pend) return fail(BZ_E_STATE, "a pending histogram was not carried along");   // (pair2 always reaches launch_pair_two_kernels)
+    if (piggy && s.pend) return fail(BZ_E_STATE, "a pending histogram was not carried along");   // (both carrier paths are always reached)
     if (deferrable) {
         s.pend = true; s.pend_hit = s.d_hit; s.pend_n = n; s.pend_counters = s.d_counters;
     } else if (h->d_hist_partial && lists_allowed) {

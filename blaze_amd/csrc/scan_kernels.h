@@ -144,6 +144,131 @@ __device__ __forceinline__ void fold_update_falsy(int ed, int end_idx, int idx, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Totals: [assigned, rows seen] go to kTotStripes striped slots behind counts[n_wl + 2] (one atomic pair per
+// workgroup) and are folded into counts[n_wl], counts[n_wl+1] by k_fold_totals before anyone reads them.
+// Per-barcode counts of one run.  Two forms:
+//  * whitelists up to kHistLdsBins barcodes: kHistBlocks workgroups each keep a private histogram of ALL bins in LDS
+//    (ds_add, no global atomics), write it to partial[block][bin], and k_hist_reduce adds the partials into counts[]
+//    (one owner per bin).  Global atomics from 8 XCDs on a 40 KB table ran at ~13 G/s = 55 us per 1M rows; this form
+//    takes a pass over hit[] at streaming rate.
+//  * larger whitelists: one global atomic per assigned row (no contention to speak of on millions of bins).
+// Both add [assigned, rows seen] to the striped totals.
+constexpr int kTotStripes = 64;
+constexpr int kHistLdsBins = 32768;
+constexpr int kHistBlocks = 64;
+constexpr int kHistThreads = 1024;
+// A run's per-barcode counts are not needed before somebody asks for them, and the two histogram kernels were 12 us of a
+// 94 us step that does nothing else meanwhile.  The engine therefore DEFERS them (blaze_hip.hip: Slot::pend): the next run
+// on the slot carries them along -- workgroups in front of k_classify_packed's grid take the private histograms of the
+// previous run's hits (its results sit in the slot's other hit buffer), workgroups in front of k_pair_candidates' grid (or
+// k_scan_seeded's: max_ed 0, 1, 3) add them into counts[] -- and whoever reads counts, list counters or timings first has the pending histogram run on its own.
+// Whitelists up to kPiggyBins barcodes (the histogram rides in k_classify_packed's dynamic LDS).
+constexpr int kPiggyBins = 12287;
+
+// one workgroup's share of k_hist_partial (kHistThreads threads, (n_wl + 1) words of dynamic LDS)
+__device__ __forceinline__ void hist_partial_block(int block, const int32_t *__restrict__ hit, int n, int n_wl,
+                                                   uint32_t *__restrict__ partial, unsigned long long *__restrict__ counts) {
+    extern __shared__ uint32_t s_bins[];                          // n_wl bins + 1 (assigned)
+    for (int b = threadIdx.x; b <= n_wl; b += kHistThreads) s_bins[b] = 0;
+    __syncthreads();
+    const int per = (((n + kHistBlocks - 1) / kHistBlocks) + 3) & ~3;     // rows per block, multiple of 4 (16-byte loads)
+    const int lo = block * per, hi = min(n, lo + per);
+    int assigned = 0;
+    // four 16-byte loads in flight per thread before their LDS atomics (one after another, a block's 15.6K rows of a 1M-row
+    // step were four dependent load -> atomics rounds per thread)
+    constexpr int kU = 4;
+    for (int i0 = lo + 4 * threadIdx.x; i0 < hi; i0 += kU * 4 * kHistThreads) {
+        int4 h[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int i = i0 + u * 4 * kHistThreads;
+            h[u] = make_int4(-1, -1, -1, -1);
+            if (i + 4 <= hi) h[u] = *(const int4 *)(hit + i);
+            else if (i < hi) {                                    // the block's ragged end (at most once per block)
+                h[u].x = hit[i];
+                if (i + 1 < hi) h[u].y = hit[i + 1];
+                if (i + 2 < hi) h[u].z = hit[i + 2];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            if (h[u].x >= 0) { atomicAdd(&s_bins[h[u].x], 1u); ++assigned; }
+            if (h[u].y >= 0) { atomicAdd(&s_bins[h[u].y], 1u); ++assigned; }
+            if (h[u].z >= 0) { atomicAdd(&s_bins[h[u].z], 1u); ++assigned; }
+            if (h[u].w >= 0) { atomicAdd(&s_bins[h[u].w], 1u); ++assigned; }
+        }
+    }
+    if (assigned) atomicAdd(&s_bins[n_wl], (uint32_t)assigned);
+    __syncthreads();
+    uint32_t *out = partial + (size_t)block * n_wl;
+    for (int b = threadIdx.x; b < n_wl; b += kHistThreads) out[b] = s_bins[b];
+    if (threadIdx.x == 0) {
+        unsigned long long *tot = counts + n_wl + 2 + 2 * (block & (kTotStripes - 1));
+        if (s_bins[n_wl]) atomicAdd(&tot[0], (unsigned long long)s_bins[n_wl]);
+        if (hi > lo) atomicAdd(&tot[1], (unsigned long long)(hi - lo));
+    }
+}
+
+__global__ __launch_bounds__(kHistThreads) void k_hist_partial(const int32_t *__restrict__ hit, int n, int n_wl,
+                                                              uint32_t *__restrict__ partial, unsigned long long *__restrict__ counts) {
+    hist_partial_block((int)blockIdx.x, hit, n, n_wl, partial, counts);
+}
+
+// End-of-run duties of the kernel that finishes a run's histogram: publish the run's list counters to the (host-mapped)
+// pinned buffer the timing call reads, and zero them: the slot's runs alternate between two counter sets, and a set is
+// clean again before the run after next appends to it (so a run needs neither a memset nor a device-to-host copy dispatch).
+__device__ __forceinline__ void finish_run(bool first_block, int32_t *cur, int32_t *host_out) {
+    if (first_block && threadIdx.x < 4) { host_out[threadIdx.x] = cur[threadIdx.x]; cur[threadIdx.x] = 0; }
+}
+
+// bins [first_bin, first_bin + n_threads): the kHistBlocks private histograms added into counts[]
+__device__ __forceinline__ void hist_reduce_bin(int b, const uint32_t *__restrict__ partial, int n_wl, unsigned long long *__restrict__ counts) {
+    if (b >= n_wl) return;
+    unsigned long long s = 0;
+#pragma unroll
+    for (int k0 = 0; k0 < kHistBlocks; k0 += 16) {               // sixteen loads in flight (all 64 cost 130 registers)
+        uint32_t v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = partial[(size_t)(k0 + k) * n_wl + b];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += v[k];
+    }
+    if (s) atomicAdd(&counts[b], s);      // the other slot's run may be adding to the same bin on its own stream
+}
+
+__global__ __launch_bounds__(256) void k_hist_reduce(const uint32_t *__restrict__ partial, int n_wl, unsigned long long *__restrict__ counts,
+                                                    int32_t *cur, int32_t *host_out) {
+    finish_run(blockIdx.x == 0, cur, host_out);
+    hist_reduce_bin((int)(blockIdx.x * blockDim.x + threadIdx.x), partial, n_wl, counts);
+}
+
+__global__ __launch_bounds__(256) void k_histogram(const int32_t *__restrict__ hit, int n, int n_wl,
+                                                  unsigned long long *__restrict__ counts,
+                                                  int32_t *cur, int32_t *host_out) {
+    __shared__ unsigned int s_assigned[4];
+    finish_run(blockIdx.x == 0, cur, host_out);
+    int assigned = 0;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const int h = hit[r];
+        if (h >= 0) { atomicAdd(&counts[h], 1ull); ++assigned; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) assigned += __shfl_down(assigned, o, 64);
+    if ((threadIdx.x & 63) == 0) s_assigned[threadIdx.x >> 6] = (unsigned int)assigned;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long a = (unsigned long long)s_assigned[0] + s_assigned[1] + s_assigned[2] + s_assigned[3];
+        const long long first = (long long)blockIdx.x * blockDim.x;
+        long long rows = 0;                                   // rows this block visited (grid-stride)
+        const long long step = (long long)gridDim.x * blockDim.x;
+        for (long long b = first; b < n; b += step) rows += min((long long)blockDim.x, (long long)n - b);
+        unsigned long long *tot = counts + n_wl + 2 + 2 * (blockIdx.x & (kTotStripes - 1));
+        if (a) atomicAdd(&tot[0], a);
+        if (rows) atomicAdd(&tot[1], (unsigned long long)rows);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Full-rate instruction selection (measured on MI355X, tools/valu_microbench.hip): with all-VGPR
 // operands v_xor/v_and/v_or/v_add_u32 and the 3-input v_bitop3_b32 issue at the SIMD-32 rate
 // (~2 cycles per wave64 instruction); v_lshlrev, v_and_or, v_or3, v_lshl_or, every v_pk_* and ANY
@@ -489,7 +614,16 @@ __global__ __launch_bounds__(256) void k_scan_seeded(
     const int32_t *__restrict__ tab, const int32_t *__restrict__ members, const uint32_t *__restrict__ planes32, int n_wl,
     const uint8_t *__restrict__ ext, int ext_stride, const uint8_t *__restrict__ ext_len,
     const int32_t *__restrict__ list, const int32_t *__restrict__ n_list_ptr, int tie,
-    int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out) {
+    int32_t *__restrict__ hit_out, int8_t *__restrict__ ed_out, int8_t *__restrict__ end_out, uint8_t *__restrict__ flags_out,
+    const uint32_t *__restrict__ red_partial, int red_n_wl, unsigned long long *__restrict__ red_counts,
+    int32_t *red_cur, int32_t *red_host) {
+    // the second half of the slot's deferred histogram (see kPiggyBins), as in front of k_pair_candidates' grid
+    const int red_blocks = red_partial ? (red_n_wl + 255) / 256 : 0;
+    if ((int)blockIdx.x < red_blocks) {                           // workgroup-uniform
+        finish_run(blockIdx.x == 0, red_cur, red_host);
+        hist_reduce_bin((int)blockIdx.x * 256 + (int)threadIdx.x, red_partial, red_n_wl, red_counts);
+        return;
+    }
     using Plan = SeedPlan<K>;
     __shared__ uint32_t fifo[kQCap][256];
     // The fold (read_assignment.py:73-85) consumes at most TWO events of each distance class, always the first two in
@@ -503,7 +637,7 @@ __global__ __launch_bounds__(256) void k_scan_seeded(
     __shared__ uint32_t events[kMaxEvents][256];
     const int n_list = *n_list_ptr;
     const int tid = threadIdx.x;
-    const int slot = blockIdx.x * blockDim.x + tid;
+    const int slot = ((int)blockIdx.x - red_blocks) * 256 + tid;
     if ((slot & ~63) >= n_list) return;                           // whole wave idle (wave-uniform)
     const bool active = slot < n_list;
     const int r = list[active ? slot : n_list - 1];
@@ -691,131 +825,6 @@ constexpr bool pair_probe_ok(int a, int b, int xi, int di) {
     const int u = x < 0 ? -x : 0, v = d < 0 ? -d : d, w = x + d - 4 > 0 ? x + d - 4 : 0;
     return u + v + w <= 2;
 }
-// ------------------------------------------------------------------------------------------
-// Totals: [assigned, rows seen] go to kTotStripes striped slots behind counts[n_wl + 2] (one atomic pair per
-// workgroup) and are folded into counts[n_wl], counts[n_wl+1] by k_fold_totals before anyone reads them.
-// Per-barcode counts of one run.  Two forms:
-//  * whitelists up to kHistLdsBins barcodes: kHistBlocks workgroups each keep a private histogram of ALL bins in LDS
-//    (ds_add, no global atomics), write it to partial[block][bin], and k_hist_reduce adds the partials into counts[]
-//    (one owner per bin).  Global atomics from 8 XCDs on a 40 KB table ran at ~13 G/s = 55 us per 1M rows; this form
-//    takes a pass over hit[] at streaming rate.
-//  * larger whitelists: one global atomic per assigned row (no contention to speak of on millions of bins).
-// Both add [assigned, rows seen] to the striped totals.
-constexpr int kTotStripes = 64;
-constexpr int kHistLdsBins = 32768;
-constexpr int kHistBlocks = 64;
-constexpr int kHistThreads = 1024;
-// A run's per-barcode counts are not needed before somebody asks for them, and the two histogram kernels were 12 us of a
-// 94 us step that does nothing else meanwhile.  The engine therefore DEFERS them (blaze_hip.hip: Slot::pend): the next run
-// on the slot carries them along -- workgroups in front of k_classify_packed's grid take the private histograms of the
-// previous run's hits (its results sit in the slot's other hit buffer), workgroups in front of k_pair_candidates' grid add
-// them into counts[] -- and whoever reads counts, list counters or timings first has the pending histogram run on its own.
-// Whitelists up to kPiggyBins barcodes (the histogram rides in k_classify_packed's dynamic LDS).
-constexpr int kPiggyBins = 12287;
-
-// one workgroup's share of k_hist_partial (kHistThreads threads, (n_wl + 1) words of dynamic LDS)
-__device__ __forceinline__ void hist_partial_block(int block, const int32_t *__restrict__ hit, int n, int n_wl,
-                                                   uint32_t *__restrict__ partial, unsigned long long *__restrict__ counts) {
-    extern __shared__ uint32_t s_bins[];                          // n_wl bins + 1 (assigned)
-    for (int b = threadIdx.x; b <= n_wl; b += kHistThreads) s_bins[b] = 0;
-    __syncthreads();
-    const int per = (((n + kHistBlocks - 1) / kHistBlocks) + 3) & ~3;     // rows per block, multiple of 4 (16-byte loads)
-    const int lo = block * per, hi = min(n, lo + per);
-    int assigned = 0;
-    // four 16-byte loads in flight per thread before their LDS atomics (one after another, a block's 15.6K rows of a 1M-row
-    // step were four dependent load -> atomics rounds per thread)
-    constexpr int kU = 4;
-    for (int i0 = lo + 4 * threadIdx.x; i0 < hi; i0 += kU * 4 * kHistThreads) {
-        int4 h[kU];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const int i = i0 + u * 4 * kHistThreads;
-            h[u] = make_int4(-1, -1, -1, -1);
-            if (i + 4 <= hi) h[u] = *(const int4 *)(hit + i);
-            else if (i < hi) {                                    // the block's ragged end (at most once per block)
-                h[u].x = hit[i];
-                if (i + 1 < hi) h[u].y = hit[i + 1];
-                if (i + 2 < hi) h[u].z = hit[i + 2];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            if (h[u].x >= 0) { atomicAdd(&s_bins[h[u].x], 1u); ++assigned; }
-            if (h[u].y >= 0) { atomicAdd(&s_bins[h[u].y], 1u); ++assigned; }
-            if (h[u].z >= 0) { atomicAdd(&s_bins[h[u].z], 1u); ++assigned; }
-            if (h[u].w >= 0) { atomicAdd(&s_bins[h[u].w], 1u); ++assigned; }
-        }
-    }
-    if (assigned) atomicAdd(&s_bins[n_wl], (uint32_t)assigned);
-    __syncthreads();
-    uint32_t *out = partial + (size_t)block * n_wl;
-    for (int b = threadIdx.x; b < n_wl; b += kHistThreads) out[b] = s_bins[b];
-    if (threadIdx.x == 0) {
-        unsigned long long *tot = counts + n_wl + 2 + 2 * (block & (kTotStripes - 1));
-        if (s_bins[n_wl]) atomicAdd(&tot[0], (unsigned long long)s_bins[n_wl]);
-        if (hi > lo) atomicAdd(&tot[1], (unsigned long long)(hi - lo));
-    }
-}
-
-__global__ __launch_bounds__(kHistThreads) void k_hist_partial(const int32_t *__restrict__ hit, int n, int n_wl,
-                                                              uint32_t *__restrict__ partial, unsigned long long *__restrict__ counts) {
-    hist_partial_block((int)blockIdx.x, hit, n, n_wl, partial, counts);
-}
-
-// End-of-run duties of the kernel that finishes a run's histogram: publish the run's list counters to the (host-mapped)
-// pinned buffer the timing call reads, and zero them: the slot's runs alternate between two counter sets, and a set is
-// clean again before the run after next appends to it (so a run needs neither a memset nor a device-to-host copy dispatch).
-__device__ __forceinline__ void finish_run(bool first_block, int32_t *cur, int32_t *host_out) {
-    if (first_block && threadIdx.x < 4) { host_out[threadIdx.x] = cur[threadIdx.x]; cur[threadIdx.x] = 0; }
-}
-
-// bins [first_bin, first_bin + n_threads): the kHistBlocks private histograms added into counts[]
-__device__ __forceinline__ void hist_reduce_bin(int b, const uint32_t *__restrict__ partial, int n_wl, unsigned long long *__restrict__ counts) {
-    if (b >= n_wl) return;
-    unsigned long long s = 0;
-#pragma unroll
-    for (int k0 = 0; k0 < kHistBlocks; k0 += 16) {               // sixteen loads in flight (all 64 cost 130 registers)
-        uint32_t v[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = partial[(size_t)(k0 + k) * n_wl + b];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s += v[k];
-    }
-    if (s) atomicAdd(&counts[b], s);      // the other slot's run may be adding to the same bin on its own stream
-}
-
-__global__ __launch_bounds__(256) void k_hist_reduce(const uint32_t *__restrict__ partial, int n_wl, unsigned long long *__restrict__ counts,
-                                                    int32_t *cur, int32_t *host_out) {
-    finish_run(blockIdx.x == 0, cur, host_out);
-    hist_reduce_bin((int)(blockIdx.x * blockDim.x + threadIdx.x), partial, n_wl, counts);
-}
-
-__global__ __launch_bounds__(256) void k_histogram(const int32_t *__restrict__ hit, int n, int n_wl,
-                                                  unsigned long long *__restrict__ counts,
-                                                  int32_t *cur, int32_t *host_out) {
-    __shared__ unsigned int s_assigned[4];
-    finish_run(blockIdx.x == 0, cur, host_out);
-    int assigned = 0;
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        const int h = hit[r];
-        if (h >= 0) { atomicAdd(&counts[h], 1ull); ++assigned; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) assigned += __shfl_down(assigned, o, 64);
-    if ((threadIdx.x & 63) == 0) s_assigned[threadIdx.x >> 6] = (unsigned int)assigned;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long a = (unsigned long long)s_assigned[0] + s_assigned[1] + s_assigned[2] + s_assigned[3];
-        const long long first = (long long)blockIdx.x * blockDim.x;
-        long long rows = 0;                                   // rows this block visited (grid-stride)
-        const long long step = (long long)gridDim.x * blockDim.x;
-        for (long long b = first; b < n; b += step) rows += min((long long)blockDim.x, (long long)n - b);
-        unsigned long long *tot = counts + n_wl + 2 + 2 * (blockIdx.x & (kTotStripes - 1));
-        if (a) atomicAdd(&tot[0], a);
-        if (rows) atomicAdd(&tot[1], (unsigned long long)rows);
-    }
-}
-
 constexpr int kPairBmWords = 2048;                                // 65536 bits per pair
 constexpr int kPairTab = 65537;
 

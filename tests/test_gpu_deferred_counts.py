@@ -1,7 +1,7 @@
 """The deferred histogram (blaze_hip.hip: Slot::pend, scan_kernels.h: kPiggyBins).
 
 A run's per-barcode counts ride along with the slot's NEXT run (workgroups in front of k_classify_packed's and
-k_pair_candidates' grids) or are flushed by whoever reads counts / list counters / timings first.  Whatever happens between
+k_pair_candidates' / k_scan_seeded's grids) or are flushed by whoever reads counts / list counters / timings first.  Whatever happens between
 two runs -- another max_ed (no carrier kernel), profiling on, a new whitelist, a reset, a bigger batch that replaces the slot's
 buffers, a fetch, the other slot, the entry point that allocates nothing -- every run is counted exactly once and the list
 counters bz_slot_timing reports are those of the LAST run.  Expectations are bincounts of the fetched hits (parity of the
@@ -63,6 +63,11 @@ def test_every_run_counted_once_whatever_comes_between(eng):
     run(0, "a", 2); run(1, "b", 2); run(0, "a", 2); run(1, "b", 2)   # both slots, each with its own pending run
     assert np.array_equal(eng.fetch(0)[0], hits["a", 2])     # a fetch in between reads the CURRENT hit buffer
     run(0, "a", 3); run(0, "a", 0); run(1, "b", 2)
+    run(0, "a", 1); run(0, "a", 1); run(0, "a", 1)            # the single-piece seeded scan carries too (max_ed 0, 1, 3) ...
+    run(1, "b", 0); run(1, "b", 3); run(1, "b", 3); run(1, "b", 2); run(1, "b", 1)   # ... and hands over to the pair kernels and back
+    eng.set_option(_lib.BZ_OPT_SCAN_MODE, 3)                 # max_ed 2 through the single-piece seeds
+    run(0, "a", 2); run(0, "a", 2)
+    eng.set_option(_lib.BZ_OPT_SCAN_MODE, 0)
     eng.set_option(_lib.BZ_OPT_PROFILE, 1)                   # profiling runs take their histogram at once
     run(0, "a", 2); run(1, "b", 2)
     t = eng.timing(0)
